@@ -1,0 +1,163 @@
+/*
+ * nerf_amd.h -- entry points this library adds to the reference's interface (C ABI).
+ *
+ * The reference keeps ray generation, sampling and positional encoding on the host and copies a
+ * [points][150] matrix to the GPU every step (train.c:176-185).  The entry points below keep the
+ * whole step on the device; each comment names the reference code it stands in for.  Functions
+ * returning int return 0 on success, 1 for a bad argument, 2 for a HIP error, 3 for an I/O error.
+ */
+#ifndef NERF_AMD_H
+#define NERF_AMD_H
+
+#include <stddef.h>
+
+#include "nerf_data.h"
+#include "nerf_mlp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime: what train.c does with cudaSetDevice / cudaMalloc / cudaMemcpy / cudaMemset /
+ * cudaFree (train.c:48,148-154,182-185,202,225,257-263), without HIP headers in the caller ------- */
+int nerf_amd_abi_version(void);
+int nerf_set_device(int device);
+int nerf_device_count(void);
+void nerf_set_stream(void* hip_stream); /* every launch of the library goes to this hipStream_t */
+void* nerf_get_stream(void);
+int nerf_stream_synchronize(void);
+void* nerf_device_malloc(size_t bytes); /* NULL on failure */
+void nerf_device_free(void* p);
+int nerf_memcpy_h2d(void* dst, const void* src, size_t bytes); /* synchronous, like cudaMemcpy */
+int nerf_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int nerf_memcpy_d2d(void* dst, const void* src, size_t bytes); /* asynchronous on the stream */
+int nerf_memset(void* dst, int value, size_t bytes);           /* asynchronous on the stream */
+int nerf_device_info(char* name256, int* compute_units, int* clock_khz, size_t* total_mem);
+
+/* per-kernel timing with events on the library's stream (no counterpart in the reference, which
+ * only wraps the whole program in `time`, Makefile:24-25) */
+void nerf_prof_enable(int on);
+void nerf_prof_reset(void);
+int nerf_prof_kernel_count(void);
+const char* nerf_prof_kernel_name(int id);
+int nerf_prof_read(int id, double* total_ms, long* launches, double* work);
+void* nerf_event_create(void);
+void nerf_event_destroy(void* e);
+int nerf_event_record(void* e);
+int nerf_event_synchronize(void* e);
+float nerf_event_elapsed_ms(void* start, void* stop);
+
+/* ---- the fp32 MFMA matrix products the MLP is made of (the reference gets them from cuBLAS Sgemm
+ * inside the mlp submodule; exported for tests and micro-benchmarks) ----------------------------- */
+/* C[M][N] = sum_k A(m,k) B(k,n);  A(m,k) = a_kc ? A[m*lda+k] : A[k*lda+m];  B(k,n) = b_kc ? B[n*ldb+k] : B[k*ldb+n]
+ * (a_kc = 0 with b_kc = 1 is not supported).  epilogue 0: store; 1: C = pre-activation and
+ * C2 = swish(C); 2: C = product .* swish'(AUX), AUX shaped like C. */
+int nerf_gemm_f32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, int M,
+                  int N, int K, int epilogue, float* C2, const float* AUX);
+/* dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]: split over the batch into slabs
+ * in d_workspace (nerf_weight_gradient_workspace bytes), then summed in a fixed order */
+size_t nerf_weight_gradient_workspace(int rows_out, int cols, long batch);
+int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, long batch, float* d_dW,
+                         float* d_workspace, int accumulate);
+
+/* ---- dataset on the device -------------------------------------------------------------------- */
+typedef struct NerfDeviceDataset NerfDeviceDataset;
+/* copies every camera and every image's RGBA8 pixels of a Dataset (data.h:25-29) to the device */
+NerfDeviceDataset* nerf_dataset_upload(const Dataset* dataset);
+/* cameras only, no pixels: enough to generate rays (d_target must then be NULL in nerf_encode_batch) */
+NerfDeviceDataset* nerf_dataset_upload_cameras(const Dataset* dataset);
+void nerf_dataset_release(NerfDeviceDataset* d);
+
+/* the three rand() draws per ray of generate_random_batch (nerf.c:168-173), in that order:
+ * idx[3*ray + {0,1,2}] = image, u, v */
+void nerf_draw_ray_indices(const Dataset* dataset, int rays_per_batch, int* idx);
+
+/* ---- encode: generate_ray + sampling + positional encoding on the device ---------------------- */
+/* stands in for generate_random_batch + batch_positional_encoding + the H2D copy
+ * (nerf.c:175-205, nerf.c:147-162, train.c:182-185).  d_pe may be NULL when only d_batch_X is wanted.  d_idx [R][3] from nerf_draw_ray_indices;
+ * d_offsets [R][S] per-sample offsets in units of one sample spacing, or NULL (the reference's
+ * deterministic spacing); d_pe [R*S][ld_pe]; d_target [R][3] (one colour per ray) or NULL;
+ * d_batch_X [R*S][6] or NULL (the reference's batch_X, if wanted). */
+int nerf_encode_batch(const NerfDeviceDataset* dataset, const int* d_idx, const float* d_offsets, int R, int S,
+                      float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe,
+                      float* d_target, float* d_batch_X);
+/* positional_encoding (nerf.c:129-145) of one device vector of any dimension:
+ * d_out [dim + 2*dim*L] */
+int nerf_encode_vector(const float* d_in, int dim, int L, float* d_out);
+/* batch_positional_encoding (nerf.c:147-162) with device pointers */
+int nerf_encode_points(const float* d_batch_X, int num_points, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe);
+/* the per-pixel ray set-up of render_test_image (nerf.c:259-280) for pixels
+ * [first_pixel, first_pixel + num_pixels) of a render_w x render_h image, row-major */
+int nerf_encode_view(const Camera* cam, int render_w, int render_h, int first_pixel, int num_pixels, int S,
+                     float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe,
+                     float* d_batch_X);
+
+/* ---- compositing on the raw MLP output (activation fused) -------------------------------------- */
+/* activation_kernel + volume_rendering_and_loss_kernel without the loss (nerf.c:7-19,21-57) in one
+ * pass over d_raw [R*S][out_dim]: target colour of ray r at d_target[r*target_stride + c].
+ * d_dens / d_rgb (both or neither) receive the activated values; d_err and d_target may be NULL
+ * (render). */
+int nerf_composite_forward(const float* d_raw, int out_dim, const float* d_target, int target_stride, float* d_dens,
+                           float* d_rgb, float* d_pixel, float* d_err, int R, int S);
+/* *d_loss += sum of squares of d_err[R][3] (nerf.c:52-59), fixed summation order */
+int nerf_loss_accumulate(const float* d_err, int R, float* d_loss);
+/* activation + volume_rendering_gradient_kernel (nerf.c:63-127) from the raw output (out_dim 4) */
+int nerf_composite_backward(const float* d_raw, int out_dim, const float* d_err, float* d_error_output, int R, int S);
+
+/* ---- trainer: the loop body of train.c:169-220 with every stage on the device ------------------ */
+typedef struct NerfTrainer NerfTrainer;
+typedef struct {
+    int rays_per_batch, num_samples;            /* train.c:16-17 */
+    float near_plane, far_plane;                /* train.c:18-19 */
+    int pos_enc_l, dir_enc_l;                   /* train.c:20-21 */
+    int hidden_dim, intermediate_dim, output_dim; /* train.c:42-44 */
+    float learning_rate;                        /* train.c:160 */
+} NerfTrainerConfig;
+
+void nerf_trainer_default_config(NerfTrainerConfig* cfg);
+/* number of weights of the two MLPs: hidden*pe + intermediate*hidden + hidden*intermediate + output*hidden */
+size_t nerf_trainer_param_count(const NerfTrainerConfig* cfg);
+/* d_param_arena: [param_count] floats or NULL; d_grad_arena: [param_count + 4] floats or NULL
+ * (slot param_count holds the step's summed squared error, so one all-reduce covers gradients and
+ * loss).  NULL arenas are allocated by the library.  Weights start uninitialised: call
+ * nerf_trainer_init_weights or nerf_trainer_set_params.  NULL on failure. */
+NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_arena, float* d_grad_arena);
+void nerf_trainer_destroy(NerfTrainer* tr);
+float* nerf_trainer_params(NerfTrainer* tr);
+float* nerf_trainer_grads(NerfTrainer* tr);
+MLP* nerf_trainer_mlp(NerfTrainer* tr, int which); /* 0: encoding -> intermediate, 1: intermediate -> output */
+/* use_rand != 0: W ~ U(-1,1)/sqrt(fan_in) from rand(), the order init_mlp would use for mlp1 then
+ * mlp2 (train.c:125-126); use_rand == 0: the same distribution from a 64-bit LCG seeded with `seed`
+ * (identical on every rank and every libc) */
+int nerf_trainer_init_weights(NerfTrainer* tr, int use_rand, unsigned long long seed);
+int nerf_trainer_set_params(NerfTrainer* tr, const float* host_params);
+int nerf_trainer_get_params(NerfTrainer* tr, float* host_params);
+/* train.c:176-216: draw-free part of one step.  Leaves the SUM over this batch of the weight
+ * gradients and of the squared error in the gradient arena. */
+int nerf_trainer_forward_backward(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
+                                  const float* d_offsets);
+/* same with host-chosen samples: d_batch_X [R*S][6] as generate_random_batch builds it, d_target [R][3] */
+int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X, const float* d_target);
+/* train.c:219-220: AdamW on gradient / grad_points for both MLPs; grad_points is rays*samples of
+ * the whole (global) batch, the reference's batch_size */
+int nerf_trainer_update(NerfTrainer* tr, float learning_rate, int grad_points);
+/* train.c:171-173 + 176-220: learning-rate decay check, forward/backward, update */
+int nerf_trainer_step(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx, const float* d_offsets);
+/* train.c:225-226: summed squared error of the last step / rays_per_batch (synchronises) */
+float nerf_trainer_last_loss(NerfTrainer* tr);
+float nerf_trainer_learning_rate(const NerfTrainer* tr);
+int nerf_trainer_steps_done(const NerfTrainer* tr);
+/* device buffers of the last step, for checking: 0 encoding [N][pe], 1 raw output [N][out],
+ * 2 pixel [R][3], 3 pixel error [R][3], 4 target [R][3], 5 dLoss/d(raw output) [N][out] */
+const float* nerf_trainer_buffer(NerfTrainer* tr, int which);
+
+/* ---- forward-only render (nerf.c:259-316 for a whole view, chunked over rays) ------------------ */
+/* host_rgb8 [render_h*render_w*3] and/or host_pixel [render_h*render_w*3] (either may be NULL) */
+int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
+                     float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
+                     unsigned char* host_rgb8, float* host_pixel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_AMD_H */

@@ -1,0 +1,103 @@
+// common.hpp -- shared declarations of the library's translation units (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define NERF_HIP_CHECK(call)                                                                             \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            fprintf(stderr, "HIP error in %s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_));      \
+            exit(EXIT_FAILURE);                                                                          \
+        }                                                                                                \
+    } while (0)
+
+// Status codes of the int-returning entry points.
+enum { NERF_OK = 0, NERF_ERR_ARG = 1, NERF_ERR_HIP = 2, NERF_ERR_IO = 3 };
+
+namespace nerf {
+
+// The stream every launch of the library goes to (set by nerf_set_stream; default: null stream).
+hipStream_t stream();
+
+// ---- per-kernel timing (off unless nerf_prof_enable(1)) ----------------------------------------
+// A ProfScope brackets the launches of one logical kernel with two events on the library's stream;
+// nerf_prof_read() sums the elapsed time per kernel id.  `work` is the algorithmic work of the
+// bracketed launches (FLOPs for the matrix products, bytes for the streaming kernels).
+enum KernelId {
+    K_ENCODE = 0,
+    K_GEMM_FWD,
+    K_GEMM_DGRAD,
+    K_GEMM_WGRAD,
+    K_REDUCE,
+    K_SKINNY_FWD,
+    K_SKINNY_BWD,
+    K_COMPOSITE_FWD,
+    K_LOSS,
+    K_COMPOSITE_BWD,
+    K_ADAMW,
+    K_COUNT
+};
+struct ProfScope {
+    ProfScope(int id, double work);
+    ~ProfScope();
+    int id_;
+    void* start_;
+    double work_;
+};
+
+// ---- fp32 MFMA matrix product ---------------------------------------------------------------
+// C = A (x) B over a contraction of length K.
+//   A element (m,k): a_kc ? A[m*lda + k] : A[k*lda + m]
+//   B element (k,n): b_kc ? B[n*ldb + k] : B[k*ldb + n]
+// Epilogues:
+enum GemmEpilogue {
+    EPI_STORE = 0,        // C[m][n] = acc
+    EPI_SWISH = 1,        // C[m][n] = acc ; C2[m][n] = swish(acc)
+    EPI_DSWISH_MUL = 2,   // C[m][n] = acc * swish'(AUX[m][n])
+    EPI_SPLITK = 3,       // slab[split][m][n] = partial acc   (reduced by reduce_slabs)
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    float* C2;        // EPI_SWISH second output
+    const float* AUX; // EPI_DSWISH_MUL input
+    int M, N, K;
+    int lda, ldb, ldc;
+    int a_kc, b_kc;
+    int epilogue;
+    int splits;       // EPI_SPLITK: number of contraction chunks (C = slabs base, chunk s at C + s*M*ldc)
+    int k_chunk;      // EPI_SPLITK: contraction rows per chunk (multiple of 32)
+};
+
+// Enqueues the product; returns NERF_OK or NERF_ERR_ARG (unsupported shape/alignment).
+int gemm_f32(const GemmArgs& args);
+
+// dst[i] = (accumulate ? dst[i] : 0) + sum_{s<splits} slabs[s*stride + i]   (fixed order: reproducible)
+void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate);
+
+// Picks the split count for a weight-gradient product with `tiles` output tiles over `rows` points.
+int choose_splits(int tiles, long rows, int* k_chunk);
+
+// ---- skinny (output_dim <= 4) layers -----------------------------------------------------------
+// Y[n][o] = sum_h Hact[n][h] * W2[o][h]
+void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim);
+// EH[n][h] = (sum_o E[n][o] W2[o][h]) * swish'(Hpre[n][h]);  dW2[o][h] (+)= sum_n E[n][o] * swish(Hpre[n][h])
+// workspace: at least skinny_backward_workspace(rows, hidden, out_dim) bytes
+size_t skinny_backward_workspace(long rows, int hidden, int out_dim);
+void skinny_backward(const float* E, const float* Hpre, const float* W2, float* EH, float* dW2, long rows,
+                     int hidden, int out_dim, float* workspace, int accumulate);
+
+// ---- AdamW -------------------------------------------------------------------------------------
+void adamw_update(float* w, const float* g, float* m, float* v, size_t n, float grad_div, float beta1,
+                  float beta2, float eps, float alpha_t, float decay);
+
+// ---- MLP internals shared by mlp.hip, trainer.hip and render.hip -------------------------------
+void adamw_scalars(float lr, float beta1, float beta2, float wd, int t, float* alpha_t, float* decay);
+
+}  // namespace nerf

@@ -1,0 +1,341 @@
+// composite.hip -- output activation, alpha compositing + loss, and the compositing gradient.
+//
+// Replaces the reference's three CUDA kernels:
+//   activation_kernel                  nerf.c:7-19   (launch train.c:192-195, nerf.c:287-290)
+//   volume_rendering_and_loss_kernel   nerf.c:21-61  (launch train.c:204-207)
+//   volume_rendering_gradient_kernel   nerf.c:63-127 (launch train.c:210-212)
+//
+// One 64-lane wavefront owns one ray.  Lane l holds the SPL = ceil(S/64) consecutive samples
+// [l*SPL, (l+1)*SPL) in registers, so a ray's S samples are read with one coalesced sweep.
+//   forward : transmittance = exclusive product scan of (1 - alpha) across the wavefront
+//             (lane-local running product, then a 6-step shuffle scan of the lane products);
+//             a sample contributes iff the transmittance in front of it is >= T_STOP, which is
+//             the reference's "accumulate, then break when T < 0.01" rule (T never increases);
+//             the pixel sum is a butterfly reduction.
+//   backward: the reference's O(S^3) density-gradient loop equals the reverse recurrence
+//             R_{S-1} = 0, R_s = (1-a_s)(a_{s+1} q_{s+1} + R_{s+1}), G_s = da_s (T_s q_s - R_s)
+//             with q_s = sum_c err_c rgb_{s,c}; it is evaluated as a reverse scan under
+//             composition of the affine maps x -> (1-a_s) x + (1-a_s) a_{s+1} q_{s+1}.
+//             No early stop here (nerf.c:77-87 has none).
+// Both kernels are HBM-bound: 16 B read (+16 B written) per sample.
+#include "common.hpp"
+#include "../../include/nerf_spec.h"
+
+namespace nerf {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// exclusive product scan over the 64 lanes of a wavefront
+__device__ __forceinline__ float wave_exclusive_product(float x, int lane) {
+    float incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float y = __shfl_up(incl, d, 64);
+        if (lane >= d) incl *= y;
+    }
+    const float ex = __shfl_up(incl, 1, 64);
+    return lane == 0 ? 1.0f : ex;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    return x;
+}
+
+// Loads one sample's density and colour.  RAW: from the MLP's raw output row (activation applied
+// here: ReLU on channel 0, sigmoid on 1..3, nerf.c:13-17).  Otherwise from dens[] / rgb[].
+template <bool RAW>
+__device__ __forceinline__ void load_sample(const float* __restrict__ raw, int out_dim, const float* __restrict__ dens,
+                                            const float* __restrict__ rgb, size_t p, float& d, float (&c)[3]) {
+    if (RAW) {
+        if (out_dim == 4) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(raw + p * 4);
+            d = fmaxf(0.0f, y[0]);
+            c[0] = sigmoid_ref(y[1]); c[1] = sigmoid_ref(y[2]); c[2] = sigmoid_ref(y[3]);
+        } else {
+            const float* y = raw + p * out_dim;
+            d = fmaxf(0.0f, y[0]);
+            c[0] = sigmoid_ref(y[1]); c[1] = sigmoid_ref(y[2]); c[2] = sigmoid_ref(y[3]);
+        }
+    } else {
+        d = dens[p];
+        c[0] = rgb[p * 3 + 0]; c[1] = rgb[p * 3 + 1]; c[2] = rgb[p * 3 + 2];
+    }
+}
+
+template <int SPL, bool RAW>
+__global__ __launch_bounds__(256) void composite_forward_kernel(
+    const float* __restrict__ raw, int out_dim, const float* __restrict__ dens_in, const float* __restrict__ rgb_in,
+    const float* __restrict__ target, int target_stride, float* __restrict__ dens_out, float* __restrict__ rgb_out,
+    float* __restrict__ pixel, float* __restrict__ err, int R, int S) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;  // whole wavefront leaves together
+
+    float alpha[SPL], col[SPL][3];
+    float local = 1.0f;
+#pragma unroll
+    for (int i = 0; i < SPL; i++) {
+        const int s = lane * SPL + i;
+        alpha[i] = 0.0f;
+        col[i][0] = col[i][1] = col[i][2] = 0.0f;
+        if (s < S) {
+            const size_t p = (size_t)ray * S + s;
+            float d;
+            load_sample<RAW>(raw, out_dim, dens_in, rgb_in, p, d, col[i]);
+            if (RAW && dens_out) {
+                dens_out[p] = d;
+                rgb_out[p * 3 + 0] = col[i][0]; rgb_out[p * 3 + 1] = col[i][1]; rgb_out[p * 3 + 2] = col[i][2];
+            }
+            alpha[i] = 1.0f - expf(-d * NERF_DELTA);  // nerf.c:35
+        }
+        local *= (1.0f - alpha[i]);
+    }
+    float T = wave_exclusive_product(local, lane);
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < SPL; i++) {
+        if (T >= NERF_T_STOP) {  // equivalent to nerf.c:42-43 because T is non-increasing
+            const float w = alpha[i] * T;
+            acc[0] += w * col[i][0]; acc[1] += w * col[i][1]; acc[2] += w * col[i][2];
+        }
+        T *= (1.0f - alpha[i]);
+    }
+    acc[0] = wave_sum(acc[0]); acc[1] = wave_sum(acc[1]); acc[2] = wave_sum(acc[2]);
+    if (lane < 3) {
+        const float a = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : acc[2]);
+        pixel[ray * 3 + lane] = a;
+        if (err) err[ray * 3 + lane] = a - target[(size_t)ray * target_stride + lane];  // nerf.c:54-55
+    }
+}
+
+// loss[0] += sum of squares of err[0..n): one workgroup, fixed summation order (reproducible;
+// the reference's atomicAdd at nerf.c:59 is order-dependent).
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ err, int n, float* loss) {
+    __shared__ float part[1024];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 1024) s += err[i] * err[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 512; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] += part[0];
+}
+
+template <int SPL, bool RAW>
+__global__ __launch_bounds__(256) void composite_backward_kernel(
+    const float* __restrict__ raw, int out_dim, const float* __restrict__ dens_in, const float* __restrict__ rgb_in,
+    const float* __restrict__ err, float* __restrict__ d_out, int R, int S) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    const float e0 = err[ray * 3 + 0], e1 = err[ray * 3 + 1], e2 = err[ray * 3 + 2];
+
+    float alpha[SPL], col[SPL][3], dens[SPL], q[SPL];
+    float local = 1.0f;
+#pragma unroll
+    for (int i = 0; i < SPL; i++) {
+        const int s = lane * SPL + i;
+        alpha[i] = 0.0f; dens[i] = 0.0f; q[i] = 0.0f;
+        col[i][0] = col[i][1] = col[i][2] = 0.0f;
+        if (s < S) {
+            const size_t p = (size_t)ray * S + s;
+            load_sample<RAW>(raw, out_dim, dens_in, rgb_in, p, dens[i], col[i]);
+            alpha[i] = 1.0f - expf(-dens[i] * NERF_DELTA);                     // nerf.c:79
+            q[i] = e0 * col[i][0] + e1 * col[i][1] + e2 * col[i][2];            // nerf.c:105-107
+        }
+        local *= (1.0f - alpha[i]);
+    }
+    // transmittance in front of each sample, no early stop (nerf.c:82-86)
+    float Tbefore[SPL];
+    {
+        float T = wave_exclusive_product(local, lane);
+#pragma unroll
+        for (int i = 0; i < SPL; i++) {
+            Tbefore[i] = T;
+            T *= (1.0f - alpha[i]);
+        }
+    }
+    // alpha*q of the sample that follows each of mine (0 past the end of the ray)
+    float aq_next[SPL];
+    {
+        const float first = alpha[0] * q[0];
+        const float from_next_lane = __shfl_down(first, 1, 64);
+#pragma unroll
+        for (int i = 0; i < SPL - 1; i++) aq_next[i] = alpha[i + 1] * q[i + 1];
+        aq_next[SPL - 1] = lane == 63 ? 0.0f : from_next_lane;
+    }
+    // this lane's composed map x -> A x + B over its samples, last sample applied first
+    float A = 1.0f, B = 0.0f;
+#pragma unroll
+    for (int i = SPL - 1; i >= 0; i--) {
+        const float a = 1.0f - alpha[i];
+        const float b = a * aq_next[i];
+        B = a * B + b;
+        A = a * A;
+    }
+    // inclusive suffix composition across lanes: G_l = F_l o F_{l+1} o ... o F_63
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float A2 = __shfl_down(A, d, 64);
+        const float B2 = __shfl_down(B, d, 64);
+        if (lane + d < 64) {
+            B = A * B2 + B;
+            A = A * A2;
+        }
+    }
+    // R entering my last sample = G_{l+1}(0)
+    float Rn = __shfl_down(B, 1, 64);
+    if (lane == 63) Rn = 0.0f;
+
+#pragma unroll
+    for (int i = SPL - 1; i >= 0; i--) {
+        const int s = lane * SPL + i;
+        const float a = 1.0f - alpha[i];
+        const float Rs = a * (aq_next[i] + Rn);
+        if (s < S) {
+            const float w = alpha[i] * Tbefore[i];                              // nerf.c:86
+            const float da = NERF_DELTA * expf(-dens[i] * NERF_DELTA);         // nerf.c:101
+            const float gd = da * (Tbefore[i] * q[i] - Rs);
+            f32x4 g;
+            g[0] = dens[i] > 0.0f ? gd : 0.0f;                                  // nerf.c:123-124
+            g[1] = (w * e0) * (col[i][0] * (1.0f - col[i][0]));                 // nerf.c:93-96
+            g[2] = (w * e1) * (col[i][1] * (1.0f - col[i][1]));
+            g[3] = (w * e2) * (col[i][2] * (1.0f - col[i][2]));
+            *reinterpret_cast<f32x4*>(d_out + ((size_t)ray * S + s) * 4) = g;
+        }
+        Rn = Rs;
+    }
+}
+
+__global__ __launch_bounds__(256) void activation_kernel(const float* __restrict__ y, float* __restrict__ dens,
+                                                         float* __restrict__ rgb, int n, int out_dim) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* o = y + (size_t)i * out_dim;
+    dens[i] = fmaxf(0.0f, o[0]);
+    rgb[i * 3 + 0] = sigmoid_ref(o[1]);
+    rgb[i * 3 + 1] = sigmoid_ref(o[2]);
+    rgb[i * 3 + 2] = sigmoid_ref(o[3]);
+}
+
+int spl_for(int S) {
+    const int need = (S + 63) / 64;
+    for (int spl = 1; spl <= 16; spl <<= 1)
+        if (need <= spl) return spl;
+    return 0;
+}
+
+template <bool RAW>
+int launch_forward(const float* raw, int out_dim, const float* dens_in, const float* rgb_in, const float* target,
+                   int target_stride, float* dens_out, float* rgb_out, float* pixel, float* err, int R, int S) {
+    const dim3 grid((R + 3) / 4), block(256);
+#define FWD(SPL)                                                                                                 \
+    hipLaunchKernelGGL((composite_forward_kernel<SPL, RAW>), grid, block, 0, stream(), raw, out_dim, dens_in,     \
+                       rgb_in, target, target_stride, dens_out, rgb_out, pixel, err, R, S)
+    switch (spl_for(S)) {
+        case 1: FWD(1); break;
+        case 2: FWD(2); break;
+        case 4: FWD(4); break;
+        case 8: FWD(8); break;
+        case 16: FWD(16); break;
+        default: return NERF_ERR_ARG;
+    }
+#undef FWD
+    return NERF_OK;
+}
+
+template <bool RAW>
+int launch_backward(const float* raw, int out_dim, const float* dens_in, const float* rgb_in, const float* err,
+                    float* d_out, int R, int S) {
+    const dim3 grid((R + 3) / 4), block(256);
+#define BWD(SPL)                                                                                                 \
+    hipLaunchKernelGGL((composite_backward_kernel<SPL, RAW>), grid, block, 0, stream(), raw, out_dim, dens_in,    \
+                       rgb_in, err, d_out, R, S)
+    switch (spl_for(S)) {
+        case 1: BWD(1); break;
+        case 2: BWD(2); break;
+        case 4: BWD(4); break;
+        case 8: BWD(8); break;
+        case 16: BWD(16); break;
+        default: return NERF_ERR_ARG;
+    }
+#undef BWD
+    return NERF_OK;
+}
+
+}  // namespace
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" {
+
+// ---- the reference's three kernels as C launchers (declared in include/nerf_kernels.h) ----------
+
+void activation_kernel_launch(float* d_layer_output, float* d_densities, float* d_colors, int batch_size,
+                              int output_dim) {
+    if (batch_size <= 0) return;
+    hipLaunchKernelGGL(activation_kernel, dim3((batch_size + 255) / 256), dim3(256), 0, stream(), d_layer_output,
+                       d_densities, d_colors, batch_size, output_dim);
+    NERF_HIP_CHECK(hipGetLastError());
+}
+
+void volume_rendering_and_loss_launch(const float* d_densities, const float* d_colors, const float* d_true_colors,
+                                      float* d_pixel_colors, float* d_pixel_errors, float* d_loss_accum,
+                                      int rays_per_batch, int num_samples) {
+    if (rays_per_batch <= 0) return;
+    if (launch_forward<false>(nullptr, 0, d_densities, d_colors, d_true_colors, num_samples * 3, nullptr, nullptr,
+                              d_pixel_colors, d_pixel_errors, rays_per_batch, num_samples) != NERF_OK) {
+        fprintf(stderr, "volume_rendering_and_loss_launch: num_samples %d not supported (max 1024)\n", num_samples);
+        exit(EXIT_FAILURE);
+    }
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream(), d_pixel_errors, rays_per_batch * 3,
+                       d_loss_accum);
+    NERF_HIP_CHECK(hipGetLastError());
+}
+
+void volume_rendering_gradient_launch(const float* d_densities, const float* d_colors, const float* d_pixel_errors,
+                                      float* d_mlp_error_output, int rays_per_batch, int num_samples) {
+    if (rays_per_batch <= 0) return;
+    if (launch_backward<false>(nullptr, 0, d_densities, d_colors, d_pixel_errors, d_mlp_error_output, rays_per_batch,
+                               num_samples) != NERF_OK) {
+        fprintf(stderr, "volume_rendering_gradient_launch: num_samples %d not supported (max 1024)\n", num_samples);
+        exit(EXIT_FAILURE);
+    }
+    NERF_HIP_CHECK(hipGetLastError());
+}
+
+// ---- fused forms used by the trainer and the renderer (declared in include/nerf_amd.h) -----------
+
+int nerf_composite_forward(const float* d_raw, int out_dim, const float* d_target, int target_stride, float* d_dens,
+                           float* d_rgb, float* d_pixel, float* d_err, int R, int S) {
+    if (R <= 0 || S <= 0 || out_dim < 4 || !d_raw || !d_pixel) return NERF_ERR_ARG;
+    if (d_err && !d_target) return NERF_ERR_ARG;
+    if ((d_dens == nullptr) != (d_rgb == nullptr)) return NERF_ERR_ARG;
+    const int rc = launch_forward<true>(d_raw, out_dim, nullptr, nullptr, d_target, target_stride, d_dens, d_rgb,
+                                        d_pixel, d_err, R, S);
+    if (rc != NERF_OK) return rc;
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+int nerf_loss_accumulate(const float* d_err, int R, float* d_loss) {
+    if (R <= 0 || !d_err || !d_loss) return NERF_ERR_ARG;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream(), d_err, R * 3, d_loss);
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+int nerf_composite_backward(const float* d_raw, int out_dim, const float* d_err, float* d_error_output, int R, int S) {
+    if (R <= 0 || S <= 0 || out_dim != 4 || !d_raw || !d_err || !d_error_output) return NERF_ERR_ARG;
+    const int rc = launch_backward<true>(d_raw, out_dim, nullptr, nullptr, d_err, d_error_output, R, S);
+    if (rc != NERF_OK) return rc;
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+}  // extern "C"

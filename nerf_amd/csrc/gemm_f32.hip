@@ -1,0 +1,371 @@
+// gemm_f32.hip -- exact-fp32 matrix products on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// These carry the MLP of the NeRF hot path: the products the reference obtains from cuBLAS Sgemm
+// inside forward_pass_mlp / backward_pass_mlp (call sites reference train.c:188-189,215-216).
+//
+// One 256-thread workgroup (4 wavefronts, 2x2) computes a 128x128 output tile; each wavefront
+// owns 64x64 of it as 2x2 MFMA tiles of 32x32 (64 accumulator registers per lane).  Operand tiles
+// of 128 x 32 are staged global -> registers -> LDS, double buffered, one barrier per K-tile; the
+// global loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them.
+//
+// Operand layouts.  "KC" = contraction index contiguous in memory (row-major [row][k]); the LDS
+// image is [128][36] floats (rows padded by 16 B so the 16 rows of a ds_read_b128 lane group fall on
+// 16 different bank slots) and a lane fetches 4 consecutive k of its row with one ds_read_b128.
+// "KS" = contraction index strided ([k][row]); the LDS image is [32][128] and a lane fetches one k
+// per ds_read_b32 (32 lanes read 32 consecutive floats: conflict free).  Inside each group of 8
+// contraction steps, MFMA j pairs k = 8g+j (lanes 0-31) with k = 8g+4+j (lanes 32-63) for both
+// operands, which is a fixed permutation of the summation order.
+//
+// The MFMA result is a k-ordered chain of fp32 fused multiply-adds: no reduced-precision inputs.
+#include "common.hpp"
+
+namespace nerf {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int KC_LD = BK + 4;            // floats per LDS row of a KC tile
+constexpr int KS_LD = 128;               // floats per LDS row of a KS tile
+constexpr int TILE_FLOATS = 128 * KC_LD; // 4608 floats; a KS tile uses the first 4096
+
+struct KernelArgs {
+    GemmArgs g;
+    int tiles_m, tiles_n;
+};
+
+// ---- global -> registers -------------------------------------------------------------------
+// A tile covers rows [x0, x0+128) of the non-contracted index (bound X) and contraction steps
+// [k0, k0+32) (bound kend).  Elements outside the bounds read as zero.
+template <bool KC, int VEC>
+__device__ __forceinline__ void load_tile(float (&s)[16], const float* __restrict__ base, int ld, int x0, int X,
+                                          int k0, int kend, int tid) {
+    constexpr int PASSES = 16 / VEC;
+    if (KC) {
+        constexpr int TPR = BK / VEC;      // threads per row
+        constexpr int RPP = 256 / TPR;     // rows per pass
+        const int kq = (tid % TPR) * VEC;
+        const int r0 = tid / TPR;
+        const int gk = k0 + kq;
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            const int row = x0 + r0 + p * RPP;
+            const bool ok = (row < X) && (gk < kend);
+            const float* src = base + (size_t)row * ld + gk;
+            if (VEC == 4) {
+                f32x4 v = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                s[p * 4 + 0] = v[0]; s[p * 4 + 1] = v[1]; s[p * 4 + 2] = v[2]; s[p * 4 + 3] = v[3];
+            } else if (VEC == 2) {
+                f32x2 v = ok ? *reinterpret_cast<const f32x2*>(src) : f32x2{0.f, 0.f};
+                s[p * 2 + 0] = v[0]; s[p * 2 + 1] = v[1];
+            } else {
+                s[p] = ok ? *src : 0.f;
+            }
+        }
+    } else {
+        constexpr int TPR = 128 / VEC;     // threads per k row
+        constexpr int RPP = 256 / TPR;     // k rows per pass
+        const int xq = (tid % TPR) * VEC;
+        const int kr0 = tid / TPR;
+        const int gx = x0 + xq;
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            const int gk = k0 + kr0 + p * RPP;
+            const bool ok = (gk < kend) && (gx < X);
+            const float* src = base + (size_t)gk * ld + gx;
+            if (VEC == 4) {
+                f32x4 v = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                s[p * 4 + 0] = v[0]; s[p * 4 + 1] = v[1]; s[p * 4 + 2] = v[2]; s[p * 4 + 3] = v[3];
+            } else if (VEC == 2) {
+                f32x2 v = ok ? *reinterpret_cast<const f32x2*>(src) : f32x2{0.f, 0.f};
+                s[p * 2 + 0] = v[0]; s[p * 2 + 1] = v[1];
+            } else {
+                s[p] = ok ? *src : 0.f;
+            }
+        }
+    }
+}
+
+// ---- registers -> LDS ----------------------------------------------------------------------
+template <bool KC, int VEC>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float (&s)[16], int tid) {
+    constexpr int PASSES = 16 / VEC;
+    if (KC) {
+        constexpr int TPR = BK / VEC;
+        constexpr int RPP = 256 / TPR;
+        const int kq = (tid % TPR) * VEC;
+        const int r0 = tid / TPR;
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            float* dst = T + (r0 + p * RPP) * KC_LD + kq;
+            if (VEC == 4)
+                *reinterpret_cast<f32x4*>(dst) = f32x4{s[p * 4 + 0], s[p * 4 + 1], s[p * 4 + 2], s[p * 4 + 3]};
+            else if (VEC == 2)
+                *reinterpret_cast<f32x2*>(dst) = f32x2{s[p * 2 + 0], s[p * 2 + 1]};
+            else
+                *dst = s[p];
+        }
+    } else {
+        constexpr int TPR = 128 / VEC;
+        constexpr int RPP = 256 / TPR;
+        const int xq = (tid % TPR) * VEC;
+        const int kr0 = tid / TPR;
+#pragma unroll
+        for (int p = 0; p < PASSES; p++) {
+            float* dst = T + (kr0 + p * RPP) * KS_LD + xq;
+            if (VEC == 4)
+                *reinterpret_cast<f32x4*>(dst) = f32x4{s[p * 4 + 0], s[p * 4 + 1], s[p * 4 + 2], s[p * 4 + 3]};
+            else if (VEC == 2)
+                *reinterpret_cast<f32x2*>(dst) = f32x2{s[p * 2 + 0], s[p * 2 + 1]};
+            else
+                *dst = s[p];
+        }
+    }
+}
+
+// ---- LDS -> MFMA fragments ---------------------------------------------------------------------
+// frag[j] feeds MFMA j of the 8-step group kk: lane l holds element (row rb + (l & 31), k = 8kk + 4(l >> 5) + j).
+template <bool KC>
+__device__ __forceinline__ void load_frag(float (&frag)[4], const float* __restrict__ T, int rb, int kk, int lane) {
+    if (KC) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(T + (rb + (lane & 31)) * KC_LD + kk * 8 + 4 * (lane >> 5));
+        frag[0] = v[0]; frag[1] = v[1]; frag[2] = v[2]; frag[3] = v[3];
+    } else {
+        const float* src = T + (kk * 8 + 4 * (lane >> 5)) * KS_LD + rb + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; j++) frag[j] = src[j * KS_LD];
+    }
+}
+
+__device__ __forceinline__ float swish_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float dswish_f(float x) {
+    const float sg = 1.0f / (1.0f + expf(-x));
+    return sg + x * sg * (1.0f - sg);
+}
+
+template <bool A_KC, bool B_KC, int AVEC, int BVEC>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const KernelArgs ka) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];
+    const GemmArgs& p = ka.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // block -> (tile_m, tile_n, split).  Blocks b and b+8 share an XCD (and its L2): consecutive
+    // slots of one XCD walk the tiles that re-read the same operand panel.
+    const int b = blockIdx.x;
+    const int ntile = ka.tiles_m * ka.tiles_n;
+    int tm, tn, split = 0;
+    if (p.epilogue == EPI_SPLITK) {
+        int tile;
+        if ((p.splits & 7) == 0) {
+            const int slot = b >> 3;
+            tile = slot % ntile;
+            split = (slot / ntile) * 8 + (b & 7);
+        } else {
+            tile = b % ntile;
+            split = b / ntile;
+        }
+        tm = tile / ka.tiles_n;
+        tn = tile % ka.tiles_n;
+    } else if ((ka.tiles_m & 7) == 0) {
+        const int slot = b >> 3;
+        tn = slot % ka.tiles_n;
+        tm = (slot / ka.tiles_n) * 8 + (b & 7);
+    } else {
+        tn = b % ka.tiles_n;
+        tm = b / ka.tiles_n;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    int kbeg = 0, kend = p.K;
+    if (p.epilogue == EPI_SPLITK) {
+        kbeg = split * p.k_chunk;
+        kend = min(p.K, kbeg + p.k_chunk);
+    }
+    const int nkt = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    float sa[16], sb[16];
+    if (nkt > 0) {
+        load_tile<A_KC, AVEC>(sa, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+        load_tile<B_KC, BVEC>(sb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+        store_tile<A_KC, AVEC>(lds[0][0], sa, tid);
+        store_tile<B_KC, BVEC>(lds[0][1], sb, tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; kt++) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            load_tile<A_KC, AVEC>(sa, p.A, p.lda, m0, p.M, k0, kend, tid);
+            load_tile<B_KC, BVEC>(sb, p.B, p.ldb, n0, p.N, k0, kend, tid);
+        }
+        const float* TA = lds[cur][0];
+        const float* TB = lds[cur][1];
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; kk++) {
+            float fa[2][4], fb[2][4];
+            load_frag<A_KC>(fa[0], TA, wm * 64, kk, lane);
+            load_frag<A_KC>(fa[1], TA, wm * 64 + 32, kk, lane);
+            load_frag<B_KC>(fb[0], TB, wn * 64, kk, lane);
+            load_frag<B_KC>(fb[1], TB, wn * 64 + 32, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][j], fb[0][j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][j], fb[1][j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][j], fb[0][j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][j], fb[1][j], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_tile<A_KC, AVEC>(lds[cur ^ 1][0], sa, tid);
+            store_tile<B_KC, BVEC>(lds[cur ^ 1][1], sb, tid);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue.  Accumulator register r of a 32x32 tile: column = lane & 31,
+    // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    float* C = p.C;
+    if (p.epilogue == EPI_SPLITK) C += (size_t)split * p.M * p.ldc;
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+            const int rbase = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < p.M && col < p.N) {
+                    const size_t o = (size_t)row * p.ldc + col;
+                    const float x = acc[mi][ni][r];
+                    if (p.epilogue == EPI_SWISH) {
+                        C[o] = x;
+                        p.C2[o] = swish_f(x);
+                    } else if (p.epilogue == EPI_DSWISH_MUL) {
+                        C[o] = x * dswish_f(p.AUX[o]);
+                    } else {
+                        C[o] = x;
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, size_t stride,
+                                                           float* __restrict__ dst, size_t n, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? dst[i] : 0.f;
+    for (int k = 0; k < splits; k++) s += slabs[(size_t)k * stride + i];
+    dst[i] = s;
+}
+
+inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
+
+// widest vector width (4, 2, 1) the operand allows
+int operand_vec(const float* ptr, int ld, int fast_extent) {
+    if (aligned_to(ptr, 16) && ld % 4 == 0 && fast_extent % 4 == 0) return 4;
+    if (aligned_to(ptr, 8) && ld % 2 == 0 && fast_extent % 2 == 0) return 2;
+    return 1;
+}
+
+template <bool A_KC, bool B_KC, int AVEC, int BVEC>
+void launch(const KernelArgs& ka, int grid) {
+    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, AVEC, BVEC>), dim3(grid), dim3(256), 0, stream(), ka);
+}
+
+}  // namespace
+
+int choose_splits(int tiles, long rows, int* k_chunk) {
+    // aim at two workgroups per CU (512 in flight), splits a multiple of 8 so that one split's
+    // tiles share an XCD, and at least 8 K-tiles of work per workgroup
+    int splits = (512 + tiles - 1) / tiles;
+    splits = ((splits + 7) / 8) * 8;
+    long max_splits = rows / (8 * BK);
+    if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits) splits = (int)max_splits;
+    if (splits >= 8) splits = (splits / 8) * 8;
+    long chunk = (rows + splits - 1) / splits;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    splits = (int)((rows + chunk - 1) / chunk);
+    *k_chunk = (int)chunk;
+    return splits;
+}
+
+int gemm_f32(const GemmArgs& g) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return NERF_ERR_ARG;
+    KernelArgs ka;
+    ka.g = g;
+    ka.tiles_m = (g.M + BM - 1) / BM;
+    ka.tiles_n = (g.N + BN - 1) / BN;
+    long grid = (long)ka.tiles_m * ka.tiles_n;
+    if (g.epilogue == EPI_SPLITK) {
+        if (g.splits <= 0 || g.k_chunk <= 0 || g.k_chunk % BK != 0) return NERF_ERR_ARG;
+        grid *= g.splits;
+    }
+    if (grid > 0x7fffffffL) return NERF_ERR_ARG;
+    const int va = operand_vec(g.A, g.lda, g.a_kc ? g.K : g.M);
+    const int vb = operand_vec(g.B, g.ldb, g.b_kc ? g.K : g.N);
+    const int gi = (int)grid;
+    if (g.a_kc && g.b_kc) {
+        if (va == 4 && vb == 4) launch<true, true, 4, 4>(ka, gi);
+        else if (va >= 2 && vb >= 2) launch<true, true, 2, 2>(ka, gi);
+        else launch<true, true, 1, 1>(ka, gi);
+    } else if (g.a_kc && !g.b_kc) {
+        if (va == 4 && vb == 4) launch<true, false, 4, 4>(ka, gi);
+        else launch<true, false, 1, 1>(ka, gi);
+    } else if (!g.a_kc && !g.b_kc) {
+        if (va == 4 && vb == 4) launch<false, false, 4, 4>(ka, gi);
+        else if (va == 4 && vb >= 2) launch<false, false, 4, 2>(ka, gi);
+        else launch<false, false, 1, 1>(ka, gi);
+    } else {
+        return NERF_ERR_ARG;  // (A strided, B contiguous) is not needed by the MLP
+    }
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {
+    const int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid), dim3(256), 0, stream(), slabs, splits, stride, dst, n,
+                       accumulate);
+}
+
+}  // namespace nerf
+
+// C-ABI access to the matrix product for tests and micro-benchmarks (declared in include/nerf_amd.h).
+extern "C" int nerf_gemm_f32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc,
+                             int M, int N, int K, int epilogue, float* C2, const float* AUX) {
+    using namespace nerf;
+    if (epilogue < EPI_STORE || epilogue > EPI_DSWISH_MUL) return NERF_ERR_ARG;
+    if (!A || !B || !C) return NERF_ERR_ARG;
+    if (epilogue == EPI_SWISH && !C2) return NERF_ERR_ARG;
+    if (epilogue == EPI_DSWISH_MUL && !AUX) return NERF_ERR_ARG;
+    GemmArgs g = {};
+    g.A = A; g.lda = lda; g.a_kc = a_kc;
+    g.B = B; g.ldb = ldb; g.b_kc = b_kc;
+    g.C = C; g.C2 = C2; g.AUX = AUX; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.epilogue = epilogue;
+    return gemm_f32(g);
+}
+
+// dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols] with the split-K path the MLP uses.
+// d_workspace: nerf_weight_gradient_workspace(...) bytes.
+extern "C" size_t nerf_weight_gradient_workspace(int rows_out, int cols, long batch) {
+    int chunk = 0;
+    const int tiles = ((rows_out + 127) / 128) * ((cols + 127) / 128);
+    const int splits = nerf::choose_splits(tiles, batch, &chunk);
+    return (size_t)splits * rows_out * cols * sizeof(float);
+}

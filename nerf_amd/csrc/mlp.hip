@@ -1,0 +1,499 @@
+// mlp.hip -- the two-layer MLP behind include/nerf_mlp.h: memory, forward, backward, AdamW.
+//
+// The reference takes this layer from its mlp/gpu submodule (cuBLAS Sgemm plus small elementwise
+// kernels); call sites: train.c:97-98,125-126,188-189,198-199,215-216,219-220,244-245,
+// nerf.c:232-243,283-284,338-339.  Here every matrix product is one of this library's fp32 MFMA
+// kernels (gemm_f32.hip) and everything elementwise is fused into a product's epilogue, except for
+// narrow output layers (output_dim <= 4, the density/colour head) which are HBM-bound streaming
+// kernels of their own:
+//   skinny_forward   Y[n][:] = Hact[n][:] W2^T            reads hidden*4 B per point
+//   skinny_backward  EH = (E W2) .* swish'(Hpre) and dW2 += E^T swish(Hpre) in ONE pass over Hpre
+//                    (reads hidden*4 B, writes hidden*4 B per point)
+#include "mlp_internal.hpp"
+#include "../../include/nerf_spec.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace nerf {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// skinny forward: 16 lanes per point, 4 points per wavefront, W2 staged in LDS once per workgroup
+// ------------------------------------------------------------------------------------------------
+template <int OUT>
+__global__ __launch_bounds__(256) void skinny_forward_kernel(const float* __restrict__ Hact,
+                                                             const float* __restrict__ W2, float* __restrict__ Y,
+                                                             long rows, int hidden) {
+    extern __shared__ __attribute__((aligned(16))) float w2s[];  // [OUT][hidden]
+    for (int i = threadIdx.x * 4; i < OUT * hidden; i += 256 * 4)
+        *reinterpret_cast<f32x4*>(w2s + i) = *reinterpret_cast<const f32x4*>(W2 + i);
+    __syncthreads();
+    const int sub = threadIdx.x & 15;
+    const long rows_per_iter = (long)gridDim.x * 16;
+    for (long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4); row < rows; row += rows_per_iter) {
+        const float* h = Hact + row * hidden;
+        float acc[OUT];
+#pragma unroll
+        for (int o = 0; o < OUT; o++) acc[o] = 0.f;
+        for (int c = sub * 4; c < hidden; c += 64) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(h + c);
+#pragma unroll
+            for (int o = 0; o < OUT; o++) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(w2s + o * hidden + c);
+                acc[o] += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < OUT; o++) {
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) acc[o] += __shfl_xor(acc[o], d, 64);
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int o = 0; o < OUT; o++) Y[row * OUT + o] = acc[o];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinny backward: thread = 4 hidden columns; a workgroup walks a contiguous chunk of points,
+// 256/(hidden/4) points at a time, keeps its dW2 partial in registers and writes one slab.
+// ------------------------------------------------------------------------------------------------
+template <int OUT>
+__global__ __launch_bounds__(256) void skinny_backward_kernel(const float* __restrict__ E,
+                                                              const float* __restrict__ Hpre,
+                                                              const float* __restrict__ W2, float* __restrict__ EH,
+                                                              float* __restrict__ slabs, long rows, int hidden,
+                                                              long rows_per_block) {
+    __shared__ f32x4 red[256];
+    const int tpr = hidden >> 2;        // threads per point
+    const int rpi = 256 / tpr;          // points per iteration
+    const int cg = threadIdx.x % tpr;   // column group
+    const int rsub = threadIdx.x / tpr;
+    f32x4 w2[OUT], acc[OUT];
+#pragma unroll
+    for (int o = 0; o < OUT; o++) {
+        w2[o] = *reinterpret_cast<const f32x4*>(W2 + (size_t)o * hidden + cg * 4);
+        acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    for (long row = r0 + rsub; row < r1; row += rpi) {
+        float e[OUT];
+#pragma unroll
+        for (int o = 0; o < OUT; o++) e[o] = E[row * OUT + o];
+        const f32x4 x = *reinterpret_cast<const f32x4*>(Hpre + row * hidden + cg * 4);
+        f32x4 eh;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float den = 1.0f + expf(-x[k]);
+            const float sg = 1.0f / den;
+            const float hact = x[k] / den;
+            const float d = sg + x[k] * sg * (1.0f - sg);
+            float back = e[0] * w2[0][k];
+#pragma unroll
+            for (int o = 1; o < OUT; o++) back += e[o] * w2[o][k];
+            eh[k] = back * d;
+#pragma unroll
+            for (int o = 0; o < OUT; o++) acc[o][k] += e[o] * hact;
+        }
+        *reinterpret_cast<f32x4*>(EH + row * hidden + cg * 4) = eh;
+    }
+    // sum the rpi partials of each column group in a fixed order, write the workgroup's slab
+    float* slab = slabs + (size_t)blockIdx.x * OUT * hidden;
+#pragma unroll
+    for (int o = 0; o < OUT; o++) {
+        __syncthreads();
+        red[threadIdx.x] = acc[o];
+        __syncthreads();
+        if (rsub == 0) {
+            f32x4 s = red[cg];
+            for (int r = 1; r < rpi; r++) {
+                const f32x4 t = red[r * tpr + cg];
+                s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+            }
+            *reinterpret_cast<f32x4*>(slab + (size_t)o * hidden + cg * 4) = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdamW.  Explicit round-to-nearest intrinsics, in the order the CPU statement of the same update
+// would take without FMA contraction, so results are bit-reproducible across host and device.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                    float grad_div, float beta1, float beta2, float eps,
+                                                    float alpha_t, float decay) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float c1 = __fsub_rn(1.0f, beta1), c2 = __fsub_rn(1.0f, beta2);
+    const float gi = __fdiv_rn(g[i], grad_div);
+    const float mi = __fadd_rn(__fmul_rn(beta1, m[i]), __fmul_rn(c1, gi));
+    const float vi = __fadd_rn(__fmul_rn(beta2, v[i]), __fmul_rn(__fmul_rn(c2, gi), gi));
+    m[i] = mi;
+    v[i] = vi;
+    const float upd = __fdiv_rn(__fmul_rn(alpha_t, mi), __fadd_rn(__fsqrt_rn(vi), eps));
+    w[i] = __fsub_rn(__fmul_rn(w[i], decay), upd);
+}
+
+bool skinny_ok(int hidden, int out_dim) {
+    if (out_dim < 1 || out_dim > 4) return false;
+    if (hidden % 4 != 0 || hidden > 1024) return false;
+    const int tpr = hidden / 4;
+    return 256 % tpr == 0;
+}
+
+int skinny_backward_blocks(long rows, int hidden) {
+    const int rpi = 256 / (hidden / 4);
+    long blocks = (rows + (long)rpi * 8 - 1) / ((long)rpi * 8);  // >= 8 iterations per workgroup
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+}  // namespace
+
+void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim) {
+    ProfScope prof(K_SKINNY_FWD, (double)rows * (hidden + out_dim) * 4.0);
+    long blocks = (rows + 127) / 128;  // 8 iterations of 16 points per workgroup
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    const size_t lds = (size_t)out_dim * hidden * sizeof(float);
+#define SKF(OUT)                                                                                               \
+    hipLaunchKernelGGL((skinny_forward_kernel<OUT>), dim3((unsigned)blocks), dim3(256), lds, stream(), Hact, W2, Y, \
+                       rows, hidden)
+    switch (out_dim) {
+        case 1: SKF(1); break;
+        case 2: SKF(2); break;
+        case 3: SKF(3); break;
+        default: SKF(4); break;
+    }
+#undef SKF
+}
+
+size_t skinny_backward_workspace(long rows, int hidden, int out_dim) {
+    return (size_t)skinny_backward_blocks(rows, hidden) * out_dim * hidden * sizeof(float);
+}
+
+void skinny_backward(const float* E, const float* Hpre, const float* W2, float* EH, float* dW2, long rows,
+                     int hidden, int out_dim, float* workspace, int accumulate) {
+    const int blocks = skinny_backward_blocks(rows, hidden);
+    const int rpi = 256 / (hidden / 4);
+    long rpb = (rows + blocks - 1) / blocks;
+    rpb = ((rpb + rpi - 1) / rpi) * rpi;
+    {
+        ProfScope prof(K_SKINNY_BWD, (double)rows * (2.0 * hidden + out_dim) * 4.0);
+#define SKB(OUT)                                                                                              \
+    hipLaunchKernelGGL((skinny_backward_kernel<OUT>), dim3(blocks), dim3(256), 0, stream(), E, Hpre, W2, EH,  \
+                       workspace, rows, hidden, rpb)
+        switch (out_dim) {
+            case 1: SKB(1); break;
+            case 2: SKB(2); break;
+            case 3: SKB(3); break;
+            default: SKB(4); break;
+        }
+#undef SKB
+    }
+    const size_t n = (size_t)out_dim * hidden;
+    ProfScope prof(K_REDUCE, (double)n * blocks * 4.0);
+    reduce_slabs(workspace, blocks, n, dW2, n, accumulate);
+}
+
+void adamw_update(float* w, const float* g, float* m, float* v, size_t n, float grad_div, float beta1, float beta2,
+                  float eps, float alpha_t, float decay) {
+    ProfScope prof(K_ADAMW, (double)n * 28.0);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), w, g, m, v, n,
+                       grad_div, beta1, beta2, eps, alpha_t, decay);
+}
+
+// ---- MLP pieces shared with the trainer --------------------------------------------------------
+
+// scalars of one AdamW step (t = step number after the increment)
+void adamw_scalars(float lr, float beta1, float beta2, float wd, int t, float* alpha_t, float* decay) {
+    const float b1t = powf(beta1, (float)t), b2t = powf(beta2, (float)t);
+    *alpha_t = lr * sqrtf(1.0f - b2t) / (1.0f - b1t);
+    *decay = 1.0f - lr * wd;
+}
+
+size_t mlp_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int batch_size) {
+    size_t need = 0;
+    int chunk = 0;
+    {  // dW1 [hidden][input]
+        const int tiles = ((hidden_dim + 127) / 128) * ((input_dim + 127) / 128);
+        const int splits = choose_splits(tiles, batch_size, &chunk);
+        need = (size_t)splits * hidden_dim * input_dim * sizeof(float);
+    }
+    size_t need2;
+    if (skinny_ok(hidden_dim, output_dim)) {
+        need2 = skinny_backward_workspace(batch_size, hidden_dim, output_dim);
+    } else {
+        const int tiles = ((output_dim + 127) / 128) * ((hidden_dim + 127) / 128);
+        const int splits = choose_splits(tiles, batch_size, &chunk);
+        need2 = (size_t)splits * output_dim * hidden_dim * sizeof(float);
+    }
+    return need > need2 ? need : need2;
+}
+
+// dW[rows_out][cols] (+)= Err[batch][rows_out]^T * Act[batch][cols]
+void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, long batch, float* dW,
+                     float* workspace, int accumulate) {
+    const int tiles = ((rows_out + 127) / 128) * ((cols + 127) / 128);
+    int chunk = 0;
+    const int splits = choose_splits(tiles, batch, &chunk);
+    GemmArgs g = {};
+    g.A = Err; g.lda = rows_out; g.a_kc = 0;
+    g.B = Act; g.ldb = cols; g.b_kc = 0;
+    g.C = workspace; g.ldc = cols;
+    g.M = rows_out; g.N = cols; g.K = (int)batch;
+    g.epilogue = EPI_SPLITK; g.splits = splits; g.k_chunk = chunk;
+    {
+        ProfScope prof(K_GEMM_WGRAD, 2.0 * rows_out * cols * (double)batch);
+        if (gemm_f32(g) != NERF_OK) {
+            fprintf(stderr, "weight_gradient: product [%d x %d] over %ld rows failed\n", rows_out, cols, batch);
+            exit(EXIT_FAILURE);
+        }
+    }
+    const size_t n = (size_t)rows_out * cols;
+    ProfScope prof(K_REDUCE, (double)n * splits * 4.0);
+    reduce_slabs(workspace, splits, n, dW, n, accumulate);
+}
+
+void mlp_forward(MLP* mlp, const float* d_X) {
+    const long B = mlp->batch_size;
+    GemmArgs g = {};
+    g.A = d_X; g.lda = mlp->input_dim; g.a_kc = 1;
+    g.B = mlp->d_W1; g.ldb = mlp->input_dim; g.b_kc = 1;
+    g.C = mlp->d_layer_preact; g.C2 = mlp->d_layer_postact; g.ldc = mlp->hidden_dim;
+    g.M = (int)B; g.N = mlp->hidden_dim; g.K = mlp->input_dim;
+    g.epilogue = EPI_SWISH;
+    {
+        ProfScope prof(K_GEMM_FWD, 2.0 * (double)B * mlp->hidden_dim * mlp->input_dim);
+        if (gemm_f32(g) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 1 failed\n"); exit(EXIT_FAILURE); }
+    }
+    if (skinny_ok(mlp->hidden_dim, mlp->output_dim)) {
+        skinny_forward(mlp->d_layer_postact, mlp->d_W2, mlp->d_layer_output, B, mlp->hidden_dim, mlp->output_dim);
+    } else {
+        GemmArgs h = {};
+        h.A = mlp->d_layer_postact; h.lda = mlp->hidden_dim; h.a_kc = 1;
+        h.B = mlp->d_W2; h.ldb = mlp->hidden_dim; h.b_kc = 1;
+        h.C = mlp->d_layer_output; h.ldc = mlp->output_dim;
+        h.M = (int)B; h.N = mlp->output_dim; h.K = mlp->hidden_dim;
+        h.epilogue = EPI_STORE;
+        ProfScope prof(K_GEMM_FWD, 2.0 * (double)B * mlp->hidden_dim * mlp->output_dim);
+        if (gemm_f32(h) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 2 failed\n"); exit(EXIT_FAILURE); }
+    }
+}
+
+// accumulate: 1 = add to the gradient buffers (the reference's contract: zero_gradients_mlp first),
+//             0 = overwrite them (saves the memset when the caller knows they are stale)
+void mlp_backward(MLP* mlp, const float* d_X, float* d_grad_X, int accumulate) {
+    const long B = mlp->batch_size;
+    const int in = mlp->input_dim, hid = mlp->hidden_dim, out = mlp->output_dim;
+    if (skinny_ok(hid, out)) {
+        skinny_backward(mlp->d_error_output, mlp->d_layer_preact, mlp->d_W2, mlp->d_error_hidden, mlp->d_W2_grad, B,
+                        hid, out, mlp->d_workspace, accumulate);
+    } else {
+        weight_gradient(mlp->d_error_output, out, mlp->d_layer_postact, hid, B, mlp->d_W2_grad, mlp->d_workspace,
+                        accumulate);
+        GemmArgs g = {};
+        g.A = mlp->d_error_output; g.lda = out; g.a_kc = 1;
+        g.B = mlp->d_W2; g.ldb = hid; g.b_kc = 0;
+        g.C = mlp->d_error_hidden; g.AUX = mlp->d_layer_preact; g.ldc = hid;
+        g.M = (int)B; g.N = hid; g.K = out;
+        g.epilogue = EPI_DSWISH_MUL;
+        ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * out);
+        if (gemm_f32(g) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: hidden error failed\n"); exit(EXIT_FAILURE); }
+    }
+    weight_gradient(mlp->d_error_hidden, hid, d_X, in, B, mlp->d_W1_grad, mlp->d_workspace, accumulate);
+    if (d_grad_X) {
+        GemmArgs g = {};
+        g.A = mlp->d_error_hidden; g.lda = hid; g.a_kc = 1;
+        g.B = mlp->d_W1; g.ldb = in; g.b_kc = 0;
+        g.C = d_grad_X; g.ldc = in;
+        g.M = (int)B; g.N = in; g.K = hid;
+        g.epilogue = EPI_STORE;
+        ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * in);
+        if (gemm_f32(g) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: input gradient failed\n"); exit(EXIT_FAILURE); }
+    }
+}
+
+// Builds an MLP whose parameter-sized buffers live where the caller says (a trainer's flat arenas)
+// or, with params == nullptr, in allocations of its own.
+MLP* mlp_create(int input_dim, int hidden_dim, int output_dim, int batch_size, void* handle, float* W1, float* W2,
+                float* g1, float* g2, float* m1, float* v1, float* m2, float* v2, bool forward_only) {
+    if (input_dim <= 0 || hidden_dim <= 0 || output_dim <= 0 || batch_size <= 0) return nullptr;
+    MLP* mlp = (MLP*)calloc(1, sizeof(MLP));
+    if (!mlp) return nullptr;
+    mlp->input_dim = input_dim; mlp->hidden_dim = hidden_dim; mlp->output_dim = output_dim;
+    mlp->batch_size = batch_size; mlp->handle = handle;
+    mlp->beta1 = NERF_ADAM_BETA1; mlp->beta2 = NERF_ADAM_BETA2; mlp->epsilon = NERF_ADAM_EPS;
+    mlp->weight_decay = NERF_ADAM_WEIGHT_DECAY; mlp->t = 0;
+    const size_t n1 = (size_t)hidden_dim * input_dim, n2 = (size_t)output_dim * hidden_dim;
+    const size_t bh = (size_t)batch_size * hidden_dim, bo = (size_t)batch_size * output_dim;
+    bool ok = true;
+    auto dalloc = [&](float** p, size_t count) {
+        if (ok && hipMalloc((void**)p, count * sizeof(float)) != hipSuccess) { *p = nullptr; ok = false; }
+    };
+    if (W1) {
+        mlp->owns_params = 0;
+        mlp->d_W1 = W1; mlp->d_W2 = W2; mlp->d_W1_grad = g1; mlp->d_W2_grad = g2;
+        mlp->d_W1_m = m1; mlp->d_W1_v = v1; mlp->d_W2_m = m2; mlp->d_W2_v = v2;
+    } else {
+        mlp->owns_params = 1;
+        dalloc(&mlp->d_W1, n1); dalloc(&mlp->d_W2, n2);
+        dalloc(&mlp->d_W1_grad, n1); dalloc(&mlp->d_W2_grad, n2);
+        dalloc(&mlp->d_W1_m, n1); dalloc(&mlp->d_W1_v, n1);
+        dalloc(&mlp->d_W2_m, n2); dalloc(&mlp->d_W2_v, n2);
+    }
+    dalloc(&mlp->d_layer_preact, bh); dalloc(&mlp->d_layer_postact, bh); dalloc(&mlp->d_layer_output, bo);
+    if (!forward_only) {
+        dalloc(&mlp->d_error_hidden, bh); dalloc(&mlp->d_error_output, bo);
+        mlp->workspace_bytes = mlp_workspace_bytes(input_dim, hidden_dim, output_dim, batch_size);
+        if (ok && hipMalloc((void**)&mlp->d_workspace, mlp->workspace_bytes) != hipSuccess) ok = false;
+    }
+    if (!ok) { free_mlp(mlp); return nullptr; }
+    if (mlp->owns_params) {
+        NERF_HIP_CHECK(hipMemsetAsync(mlp->d_W1_grad, 0, n1 * 4, stream()));
+        NERF_HIP_CHECK(hipMemsetAsync(mlp->d_W2_grad, 0, n2 * 4, stream()));
+        NERF_HIP_CHECK(hipMemsetAsync(mlp->d_W1_m, 0, n1 * 4, stream()));
+        NERF_HIP_CHECK(hipMemsetAsync(mlp->d_W1_v, 0, n1 * 4, stream()));
+        NERF_HIP_CHECK(hipMemsetAsync(mlp->d_W2_m, 0, n2 * 4, stream()));
+        NERF_HIP_CHECK(hipMemsetAsync(mlp->d_W2_v, 0, n2 * 4, stream()));
+    }
+    return mlp;
+}
+
+}  // namespace nerf
+
+using namespace nerf;
+
+extern "C" {
+
+// W ~ U(-1,1) / sqrtf(fan_in), drawn with rand() so srand() in the caller controls it as it does in
+// the reference (train.c:13).
+static void host_init_weights(float* w, int fan_out, int fan_in) {
+    const float scale = 1.0f / sqrtf((float)fan_in);
+    for (size_t i = 0; i < (size_t)fan_out * fan_in; i++)
+        w[i] = (((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f) * scale;
+}
+
+MLP* init_mlp(int input_dim, int hidden_dim, int output_dim, int batch_size, void* handle) {
+    MLP* mlp = mlp_create(input_dim, hidden_dim, output_dim, batch_size, handle, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, false);
+    if (!mlp) return nullptr;
+    const size_t n1 = (size_t)hidden_dim * input_dim, n2 = (size_t)output_dim * hidden_dim;
+    float* h = (float*)malloc((n1 > n2 ? n1 : n2) * sizeof(float));
+    host_init_weights(h, hidden_dim, input_dim);
+    NERF_HIP_CHECK(hipMemcpy(mlp->d_W1, h, n1 * 4, hipMemcpyHostToDevice));
+    host_init_weights(h, output_dim, hidden_dim);
+    NERF_HIP_CHECK(hipMemcpy(mlp->d_W2, h, n2 * 4, hipMemcpyHostToDevice));
+    free(h);
+    return mlp;
+}
+
+void free_mlp(MLP* mlp) {
+    if (!mlp) return;
+    if (mlp->owns_params) {
+        hipFree(mlp->d_W1); hipFree(mlp->d_W2); hipFree(mlp->d_W1_grad); hipFree(mlp->d_W2_grad);
+        hipFree(mlp->d_W1_m); hipFree(mlp->d_W1_v); hipFree(mlp->d_W2_m); hipFree(mlp->d_W2_v);
+    }
+    hipFree(mlp->d_layer_preact); hipFree(mlp->d_layer_postact); hipFree(mlp->d_layer_output);
+    hipFree(mlp->d_error_hidden); hipFree(mlp->d_error_output); hipFree(mlp->d_workspace);
+    free(mlp);
+}
+
+void forward_pass_mlp(MLP* mlp, float* d_X) {
+    mlp_forward(mlp, d_X);
+    NERF_HIP_CHECK(hipGetLastError());
+}
+
+void zero_gradients_mlp(MLP* mlp) {
+    NERF_HIP_CHECK(hipMemsetAsync(mlp->d_W1_grad, 0, (size_t)mlp->hidden_dim * mlp->input_dim * 4, stream()));
+    NERF_HIP_CHECK(hipMemsetAsync(mlp->d_W2_grad, 0, (size_t)mlp->output_dim * mlp->hidden_dim * 4, stream()));
+}
+
+void backward_pass_mlp(MLP* mlp, float* d_X, float* d_grad_X) {
+    mlp_backward(mlp, d_X, d_grad_X, 1);
+    NERF_HIP_CHECK(hipGetLastError());
+}
+
+void update_weights_mlp(MLP* mlp, float learning_rate) {
+    mlp->t++;
+    float alpha_t, decay;
+    adamw_scalars(learning_rate, mlp->beta1, mlp->beta2, mlp->weight_decay, mlp->t, &alpha_t, &decay);
+    const float div = (float)mlp->batch_size;
+    adamw_update(mlp->d_W1, mlp->d_W1_grad, mlp->d_W1_m, mlp->d_W1_v, (size_t)mlp->hidden_dim * mlp->input_dim, div,
+                 mlp->beta1, mlp->beta2, mlp->epsilon, alpha_t, decay);
+    adamw_update(mlp->d_W2, mlp->d_W2_grad, mlp->d_W2_m, mlp->d_W2_v, (size_t)mlp->output_dim * mlp->hidden_dim, div,
+                 mlp->beta1, mlp->beta2, mlp->epsilon, alpha_t, decay);
+    NERF_HIP_CHECK(hipGetLastError());
+}
+
+// ---- checkpoint: this library's own format (the reference's lives in its absent submodule) -------
+// header: magic, version, input_dim, hidden_dim, output_dim, batch_size, t   (7 x int32)
+// body  : W1, W2, W1_m, W1_v, W2_m, W2_v                                      (fp32, row-major)
+void save_mlp(MLP* mlp, const char* filename) {
+    FILE* f = fopen(filename, "wb");
+    if (!f) { printf("Error: could not open %s for writing\n", filename); return; }
+    const size_t n1 = (size_t)mlp->hidden_dim * mlp->input_dim, n2 = (size_t)mlp->output_dim * mlp->hidden_dim;
+    int32_t hdr[7] = {(int32_t)NERF_CKPT_MAGIC, NERF_CKPT_VERSION, mlp->input_dim, mlp->hidden_dim,
+                      mlp->output_dim,          mlp->batch_size,   mlp->t};
+    fwrite(hdr, sizeof(hdr), 1, f);
+    float* h = (float*)malloc((n1 > n2 ? n1 : n2) * sizeof(float));
+    const float* parts[6] = {mlp->d_W1, mlp->d_W2, mlp->d_W1_m, mlp->d_W1_v, mlp->d_W2_m, mlp->d_W2_v};
+    const size_t counts[6] = {n1, n2, n1, n1, n2, n2};
+    NERF_HIP_CHECK(hipStreamSynchronize(stream()));
+    for (int i = 0; i < 6; i++) {
+        NERF_HIP_CHECK(hipMemcpy(h, parts[i], counts[i] * 4, hipMemcpyDeviceToHost));
+        fwrite(h, 4, counts[i], f);
+    }
+    free(h);
+    fclose(f);
+    printf("Model saved to %s\n", filename);
+}
+
+MLP* load_mlp(const char* filename, int custom_batch_size, void* handle) {
+    FILE* f = fopen(filename, "rb");
+    if (!f) { printf("Error: could not open %s\n", filename); return nullptr; }
+    int32_t hdr[7];
+    if (fread(hdr, sizeof(hdr), 1, f) != 1 || (uint32_t)hdr[0] != NERF_CKPT_MAGIC || hdr[1] != NERF_CKPT_VERSION) {
+        printf("Error: %s is not a model file of this library\n", filename);
+        fclose(f);
+        return nullptr;
+    }
+    const int batch = custom_batch_size > 0 ? custom_batch_size : hdr[5];
+    MLP* mlp = mlp_create(hdr[2], hdr[3], hdr[4], batch, handle, nullptr, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, false);
+    if (!mlp) { fclose(f); return nullptr; }
+    mlp->t = hdr[6];
+    const size_t n1 = (size_t)mlp->hidden_dim * mlp->input_dim, n2 = (size_t)mlp->output_dim * mlp->hidden_dim;
+    float* h = (float*)malloc((n1 > n2 ? n1 : n2) * sizeof(float));
+    float* parts[6] = {mlp->d_W1, mlp->d_W2, mlp->d_W1_m, mlp->d_W1_v, mlp->d_W2_m, mlp->d_W2_v};
+    const size_t counts[6] = {n1, n2, n1, n1, n2, n2};
+    for (int i = 0; i < 6; i++) {
+        if (fread(h, 4, counts[i], f) != counts[i]) {
+            printf("Error: %s is truncated\n", filename);
+            free(h); fclose(f); free_mlp(mlp);
+            return nullptr;
+        }
+        NERF_HIP_CHECK(hipMemcpy(parts[i], h, counts[i] * 4, hipMemcpyHostToDevice));
+    }
+    free(h);
+    fclose(f);
+    printf("Model loaded from %s\n", filename);
+    return mlp;
+}
+
+}  // extern "C"
+
+// C-ABI access to the split-K weight-gradient product (declared in include/nerf_amd.h).
+extern "C" int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, long batch,
+                                    float* d_dW, float* d_workspace, int accumulate) {
+    if (!d_err || !d_act || !d_dW || !d_workspace || rows_out <= 0 || cols <= 0 || batch <= 0) return NERF_ERR_ARG;
+    nerf::weight_gradient(d_err, rows_out, d_act, cols, batch, d_dW, d_workspace, accumulate);
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}

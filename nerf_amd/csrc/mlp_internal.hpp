@@ -1,0 +1,17 @@
+// mlp_internal.hpp -- MLP helpers shared by mlp.hip, trainer.hip and render.hip (not part of the C ABI).
+#pragma once
+#include "common.hpp"
+#include "../../include/nerf_mlp.h"
+
+namespace nerf {
+
+// An MLP whose weight/gradient/moment buffers are the given device pointers (W1 != nullptr: the
+// caller keeps ownership) or fresh allocations (W1 == nullptr).  forward_only skips the error
+// buffers and the weight-gradient workspace.
+MLP* mlp_create(int input_dim, int hidden_dim, int output_dim, int batch_size, void* handle, float* W1, float* W2,
+                float* g1, float* g2, float* m1, float* v1, float* m2, float* v2, bool forward_only);
+void mlp_forward(MLP* mlp, const float* d_X);
+// accumulate = 1: add to the gradient buffers; 0: overwrite them
+void mlp_backward(MLP* mlp, const float* d_X, float* d_grad_X, int accumulate);
+
+}  // namespace nerf

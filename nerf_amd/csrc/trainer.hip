@@ -1,0 +1,337 @@
+// trainer.hip -- one training step entirely on the device, and the forward-only renderer.
+//
+// Stands in for the body of the reference's training loop (train.c:169-220) and for
+// render_test_image's per-pixel loop (nerf.c:259-320).  The call order is the reference's:
+//   learning-rate decay check        train.c:171-173
+//   batch + encoding                 train.c:176-185   -> encode_kernel (device)
+//   forward mlp1, mlp2               train.c:188-189   -> MFMA products
+//   activation                       train.c:192-195   -> fused into the compositing kernels
+//   zero gradients                   train.c:198-199   -> not needed: the weight-gradient reduce overwrites
+//   loss = 0                         train.c:202
+//   compositing + loss               train.c:204-207
+//   compositing gradient             train.c:210-212   -> written into mlp2->d_error_output (train.c:156)
+//   backward mlp2, mlp1              train.c:215-216
+//   AdamW update                     train.c:219-220   -> one launch over the flat parameter arena
+// Weights, gradients and both AdamW moments of the two MLPs live in four flat arenas with the
+// layout [mlp1.W1 | mlp1.W2 | mlp2.W1 | mlp2.W2]; the gradient arena has one extra slot for the
+// summed squared error so that a data-parallel caller all-reduces a single buffer.
+#include "mlp_internal.hpp"
+#include "../../include/nerf_amd.h"
+#include "../../include/nerf_kernels.h"
+#include "../../include/nerf_spec.h"
+
+#include <math.h>
+#include <string.h>
+
+using namespace nerf;
+
+struct NerfTrainer {
+    NerfTrainerConfig cfg;
+    int pe_dim;
+    size_t n_params;
+    size_t off[4];  // arena offsets of mlp1.W1, mlp1.W2, mlp2.W1, mlp2.W2
+    float* d_params;
+    float* d_grads;  // n_params + 4
+    float* d_m;
+    float* d_v;
+    int owns_params, owns_grads;
+    MLP* mlp1;
+    MLP* mlp2;
+    float* d_pe;      // [N][pe_dim]
+    float* d_target;  // [R][3]
+    float* d_pixel;   // [R][3]
+    float* d_err;     // [R][3]
+    float learning_rate;
+    int steps;
+};
+
+namespace {
+
+__global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ pix, unsigned char* __restrict__ out,
+                                                       int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // nerf.c:314-315: (unsigned char)(fminf(1, fmaxf(0, c)) * 255), truncating
+    out[i] = (unsigned char)__fmul_rn(fminf(1.0f, fmaxf(0.0f, pix[i])), 255.0f);
+}
+
+unsigned long long lcg_next(unsigned long long* st) {
+    *st = *st * 6364136223846793005ULL + 1442695040888963407ULL;
+    return *st;
+}
+
+void fill_lcg(float* w, int fan_out, int fan_in, unsigned long long seed) {
+    unsigned long long st = seed;
+    const float scale = 1.0f / sqrtf((float)fan_in);
+    for (size_t i = 0; i < (size_t)fan_out * fan_in; i++) {
+        const float u = (float)(lcg_next(&st) >> 40) * (1.0f / 16777216.0f);
+        w[i] = (u * 2.0f - 1.0f) * scale;
+    }
+}
+
+void fill_rand(float* w, int fan_out, int fan_in) {
+    const float scale = 1.0f / sqrtf((float)fan_in);
+    for (size_t i = 0; i < (size_t)fan_out * fan_in; i++)
+        w[i] = (((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f) * scale;
+}
+
+int after_forward(NerfTrainer* tr) {
+    const int R = tr->cfg.rays_per_batch, S = tr->cfg.num_samples;
+    float* loss = tr->d_grads + tr->n_params;
+    mlp_forward(tr->mlp1, tr->d_pe);
+    mlp_forward(tr->mlp2, tr->mlp1->d_layer_output);
+    if (hipMemsetAsync(loss, 0, 4 * sizeof(float), stream()) != hipSuccess) return NERF_ERR_HIP;
+    int rc;
+    {
+        ProfScope prof(K_COMPOSITE_FWD, (double)R * S * 16.0 + (double)R * 36.0);
+        rc = nerf_composite_forward(tr->mlp2->d_layer_output, tr->cfg.output_dim, tr->d_target, 3, nullptr, nullptr,
+                                    tr->d_pixel, tr->d_err, R, S);
+    }
+    if (rc != NERF_OK) return rc;
+    {
+        ProfScope prof(K_LOSS, (double)R * 12.0);
+        rc = nerf_loss_accumulate(tr->d_err, R, loss);
+    }
+    if (rc != NERF_OK) return rc;
+    {
+        ProfScope prof(K_COMPOSITE_BWD, (double)R * S * 32.0 + (double)R * 12.0);
+        rc = nerf_composite_backward(tr->mlp2->d_layer_output, tr->cfg.output_dim, tr->d_err,
+                                     tr->mlp2->d_error_output, R, S);
+    }
+    if (rc != NERF_OK) return rc;
+    mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp1->d_error_output, 0);
+    mlp_backward(tr->mlp1, tr->d_pe, nullptr, 0);
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+void nerf_trainer_default_config(NerfTrainerConfig* cfg) {
+    cfg->rays_per_batch = NERF_DEFAULT_RAYS_PER_BATCH;
+    cfg->num_samples = NERF_DEFAULT_NUM_SAMPLES;
+    cfg->near_plane = NERF_DEFAULT_NEAR;
+    cfg->far_plane = NERF_DEFAULT_FAR;
+    cfg->pos_enc_l = NERF_DEFAULT_POS_ENC_L;
+    cfg->dir_enc_l = NERF_DEFAULT_DIR_ENC_L;
+    cfg->hidden_dim = NERF_DEFAULT_HIDDEN_DIM;
+    cfg->intermediate_dim = NERF_DEFAULT_INTERMEDIATE_DIM;
+    cfg->output_dim = NERF_DEFAULT_OUTPUT_DIM;
+    cfg->learning_rate = NERF_DEFAULT_LR;
+}
+
+size_t nerf_trainer_param_count(const NerfTrainerConfig* c) {
+    const size_t pe = NERF_PE_DIM3(c->pos_enc_l) + NERF_PE_DIM3(c->dir_enc_l);
+    return (size_t)c->hidden_dim * pe + (size_t)c->intermediate_dim * c->hidden_dim +
+           (size_t)c->hidden_dim * c->intermediate_dim + (size_t)c->output_dim * c->hidden_dim;
+}
+
+NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_arena, float* d_grad_arena) {
+    if (!cfg || cfg->rays_per_batch <= 0 || cfg->num_samples <= 1 || cfg->num_samples > 1024 ||
+        cfg->output_dim != 4 || cfg->hidden_dim <= 0 || cfg->intermediate_dim <= 0)
+        return nullptr;
+    if ((long long)cfg->rays_per_batch * cfg->num_samples > 0x7fffffffLL) return nullptr;
+    NerfTrainer* tr = (NerfTrainer*)calloc(1, sizeof(NerfTrainer));
+    if (!tr) return nullptr;
+    tr->cfg = *cfg;
+    tr->pe_dim = NERF_PE_DIM3(cfg->pos_enc_l) + NERF_PE_DIM3(cfg->dir_enc_l);
+    tr->n_params = nerf_trainer_param_count(cfg);
+    const int H = cfg->hidden_dim, M = cfg->intermediate_dim, O = cfg->output_dim;
+    tr->off[0] = 0;
+    tr->off[1] = tr->off[0] + (size_t)H * tr->pe_dim;
+    tr->off[2] = tr->off[1] + (size_t)M * H;
+    tr->off[3] = tr->off[2] + (size_t)H * M;
+    const int R = cfg->rays_per_batch, N = R * cfg->num_samples;
+    bool ok = true;
+    auto dalloc = [&](float** p, size_t count) {
+        if (ok && hipMalloc((void**)p, count * sizeof(float)) != hipSuccess) { *p = nullptr; ok = false; }
+    };
+    if (d_param_arena) tr->d_params = d_param_arena; else { dalloc(&tr->d_params, tr->n_params); tr->owns_params = 1; }
+    if (d_grad_arena) tr->d_grads = d_grad_arena; else { dalloc(&tr->d_grads, tr->n_params + 4); tr->owns_grads = 1; }
+    dalloc(&tr->d_m, tr->n_params);
+    dalloc(&tr->d_v, tr->n_params);
+    dalloc(&tr->d_pe, (size_t)N * tr->pe_dim);
+    dalloc(&tr->d_target, (size_t)R * 3);
+    dalloc(&tr->d_pixel, (size_t)R * 3);
+    dalloc(&tr->d_err, (size_t)R * 3);
+    if (ok) {
+        float *P = tr->d_params, *G = tr->d_grads, *Mo = tr->d_m, *V = tr->d_v;
+        const size_t* o = tr->off;
+        tr->mlp1 = mlp_create(tr->pe_dim, H, M, N, nullptr, P + o[0], P + o[1], G + o[0], G + o[1], Mo + o[0], V + o[0],
+                              Mo + o[1], V + o[1], false);
+        tr->mlp2 = mlp_create(M, H, O, N, nullptr, P + o[2], P + o[3], G + o[2], G + o[3], Mo + o[2], V + o[2],
+                              Mo + o[3], V + o[3], false);
+        ok = tr->mlp1 && tr->mlp2;
+    }
+    if (!ok) { nerf_trainer_destroy(tr); return nullptr; }
+    NERF_HIP_CHECK(hipMemsetAsync(tr->d_m, 0, tr->n_params * 4, stream()));
+    NERF_HIP_CHECK(hipMemsetAsync(tr->d_v, 0, tr->n_params * 4, stream()));
+    NERF_HIP_CHECK(hipMemsetAsync(tr->d_grads, 0, (tr->n_params + 4) * 4, stream()));
+    tr->learning_rate = cfg->learning_rate;
+    tr->steps = 0;
+    return tr;
+}
+
+void nerf_trainer_destroy(NerfTrainer* tr) {
+    if (!tr) return;
+    if (tr->mlp1) free_mlp(tr->mlp1);
+    if (tr->mlp2) free_mlp(tr->mlp2);
+    if (tr->owns_params) hipFree(tr->d_params);
+    if (tr->owns_grads) hipFree(tr->d_grads);
+    hipFree(tr->d_m); hipFree(tr->d_v); hipFree(tr->d_pe);
+    hipFree(tr->d_target); hipFree(tr->d_pixel); hipFree(tr->d_err);
+    free(tr);
+}
+
+float* nerf_trainer_params(NerfTrainer* tr) { return tr->d_params; }
+float* nerf_trainer_grads(NerfTrainer* tr) { return tr->d_grads; }
+MLP* nerf_trainer_mlp(NerfTrainer* tr, int which) { return which == 0 ? tr->mlp1 : (which == 1 ? tr->mlp2 : nullptr); }
+
+int nerf_trainer_init_weights(NerfTrainer* tr, int use_rand, unsigned long long seed) {
+    float* h = (float*)malloc(tr->n_params * sizeof(float));
+    if (!h) return NERF_ERR_ARG;
+    const int H = tr->cfg.hidden_dim, M = tr->cfg.intermediate_dim, O = tr->cfg.output_dim;
+    const int fan_out[4] = {H, M, H, O}, fan_in[4] = {tr->pe_dim, H, M, H};
+    for (int i = 0; i < 4; i++) {
+        if (use_rand) fill_rand(h + tr->off[i], fan_out[i], fan_in[i]);
+        else fill_lcg(h + tr->off[i], fan_out[i], fan_in[i], seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)i);
+    }
+    const int rc = nerf_trainer_set_params(tr, h);
+    free(h);
+    return rc;
+}
+
+int nerf_trainer_set_params(NerfTrainer* tr, const float* host_params) {
+    return nerf_memcpy_h2d(tr->d_params, host_params, tr->n_params * sizeof(float));
+}
+
+int nerf_trainer_get_params(NerfTrainer* tr, float* host_params) {
+    return nerf_memcpy_d2h(host_params, tr->d_params, tr->n_params * sizeof(float));
+}
+
+int nerf_trainer_forward_backward(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
+                                  const float* d_offsets) {
+    if (!tr || !dataset || !d_idx) return NERF_ERR_ARG;
+    const NerfTrainerConfig& c = tr->cfg;
+    int rc;
+    {
+        ProfScope prof(K_ENCODE, (double)c.rays_per_batch * c.num_samples * tr->pe_dim * 4.0);
+        rc = nerf_encode_batch(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane, c.far_plane,
+                               c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_dim, tr->d_target, nullptr);
+    }
+    if (rc != NERF_OK) return rc;
+    return after_forward(tr);
+}
+
+int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X, const float* d_target) {
+    if (!tr || !d_batch_X || !d_target) return NERF_ERR_ARG;
+    const NerfTrainerConfig& c = tr->cfg;
+    const int N = c.rays_per_batch * c.num_samples;
+    int rc;
+    {
+        ProfScope prof(K_ENCODE, (double)N * tr->pe_dim * 4.0);
+        rc = nerf_encode_points(d_batch_X, N, c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_dim);
+    }
+    if (rc != NERF_OK) return rc;
+    if (hipMemcpyAsync(tr->d_target, d_target, (size_t)c.rays_per_batch * 3 * sizeof(float), hipMemcpyDeviceToDevice,
+                       stream()) != hipSuccess)
+        return NERF_ERR_HIP;
+    return after_forward(tr);
+}
+
+int nerf_trainer_update(NerfTrainer* tr, float learning_rate, int grad_points) {
+    if (!tr || grad_points <= 0) return NERF_ERR_ARG;
+    tr->mlp1->t++;
+    tr->mlp2->t++;
+    float alpha_t, decay;
+    adamw_scalars(learning_rate, tr->mlp1->beta1, tr->mlp1->beta2, tr->mlp1->weight_decay, tr->mlp1->t, &alpha_t,
+                  &decay);
+    adamw_update(tr->d_params, tr->d_grads, tr->d_m, tr->d_v, tr->n_params, (float)grad_points, tr->mlp1->beta1,
+                 tr->mlp1->beta2, tr->mlp1->epsilon, alpha_t, decay);
+    tr->steps++;
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+int nerf_trainer_step(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx, const float* d_offsets) {
+    if (!tr) return NERF_ERR_ARG;
+    if (tr->mlp1->t % NERF_LR_DECAY_EVERY == 0) tr->learning_rate *= NERF_LR_DECAY;  // train.c:171-173
+    const int rc = nerf_trainer_forward_backward(tr, dataset, d_idx, d_offsets);
+    if (rc != NERF_OK) return rc;
+    return nerf_trainer_update(tr, tr->learning_rate, tr->cfg.rays_per_batch * tr->cfg.num_samples);
+}
+
+float nerf_trainer_last_loss(NerfTrainer* tr) {
+    float sse = 0.0f;
+    if (nerf_memcpy_d2h(&sse, tr->d_grads + tr->n_params, sizeof(float)) != NERF_OK) return NAN;
+    return sse / (float)tr->cfg.rays_per_batch;  // train.c:226
+}
+
+float nerf_trainer_learning_rate(const NerfTrainer* tr) { return tr->learning_rate; }
+int nerf_trainer_steps_done(const NerfTrainer* tr) { return tr->mlp1->t; }
+
+const float* nerf_trainer_buffer(NerfTrainer* tr, int which) {
+    switch (which) {
+        case 0: return tr->d_pe;
+        case 1: return tr->mlp2->d_layer_output;
+        case 2: return tr->d_pixel;
+        case 3: return tr->d_err;
+        case 4: return tr->d_target;
+        case 5: return tr->mlp2->d_error_output;
+        default: return nullptr;
+    }
+}
+
+int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
+                     float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
+                     unsigned char* host_rgb8, float* host_pixel) {
+    if (!mlp1 || !mlp2 || !cam || render_w <= 0 || render_h <= 0 || num_samples <= 1 || num_samples > 1024)
+        return NERF_ERR_ARG;
+    const int pe_dim = NERF_PE_DIM3(pos_enc_l) + NERF_PE_DIM3(dir_enc_l);
+    if (mlp1->input_dim != pe_dim || mlp2->input_dim != mlp1->output_dim || mlp2->output_dim < 4) return NERF_ERR_ARG;
+    const int total = render_w * render_h;
+    if (rays_per_chunk <= 0) rays_per_chunk = 4096;
+    if (rays_per_chunk > total) rays_per_chunk = total;
+    const int N = rays_per_chunk * num_samples;
+    // forward-only views of the two MLPs sharing the trained weights (the reference clones the
+    // weights into batch-128 MLPs instead, nerf.c:232-243)
+    MLP* r1 = mlp_create(mlp1->input_dim, mlp1->hidden_dim, mlp1->output_dim, N, nullptr, mlp1->d_W1, mlp1->d_W2,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+    MLP* r2 = mlp_create(mlp2->input_dim, mlp2->hidden_dim, mlp2->output_dim, N, nullptr, mlp2->d_W1, mlp2->d_W2,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+    float *d_pe = nullptr, *d_pixel = nullptr;
+    unsigned char* d_rgb8 = nullptr;
+    int rc = NERF_OK;
+    if (!r1 || !r2 || hipMalloc((void**)&d_pe, (size_t)N * pe_dim * 4) != hipSuccess ||
+        hipMalloc((void**)&d_pixel, (size_t)total * 3 * 4) != hipSuccess ||
+        hipMalloc((void**)&d_rgb8, (size_t)total * 3) != hipSuccess)
+        rc = NERF_ERR_HIP;
+    for (int first = 0; rc == NERF_OK && first < total; first += rays_per_chunk) {
+        const int count = (total - first) < rays_per_chunk ? (total - first) : rays_per_chunk;
+        // a short last chunk still runs the MLPs at the full chunk size; the extra rows are ignored
+        {
+            ProfScope prof(K_ENCODE, (double)count * num_samples * pe_dim * 4.0);
+            rc = nerf_encode_view(cam, render_w, render_h, first, count, num_samples, near_plane, far_plane, pos_enc_l,
+                                  dir_enc_l, d_pe, pe_dim, nullptr);
+        }
+        if (rc != NERF_OK) break;
+        mlp_forward(r1, d_pe);
+        mlp_forward(r2, r1->d_layer_output);
+        ProfScope prof(K_COMPOSITE_FWD, (double)count * num_samples * 16.0);
+        rc = nerf_composite_forward(r2->d_layer_output, r2->output_dim, nullptr, 0, nullptr, nullptr,
+                                    d_pixel + (size_t)first * 3, nullptr, count, num_samples);
+    }
+    if (rc == NERF_OK) {
+        hipLaunchKernelGGL(quantize_kernel, dim3((total * 3 + 255) / 256), dim3(256), 0, stream(), d_pixel, d_rgb8,
+                           total * 3);
+        if (host_pixel) rc = nerf_memcpy_d2h(host_pixel, d_pixel, (size_t)total * 3 * 4);
+        if (rc == NERF_OK && host_rgb8) rc = nerf_memcpy_d2h(host_rgb8, d_rgb8, (size_t)total * 3);
+        if (rc == NERF_OK && hipStreamSynchronize(stream()) != hipSuccess) rc = NERF_ERR_HIP;
+    }
+    if (r1) free_mlp(r1);
+    if (r2) free_mlp(r2);
+    hipFree(d_pe); hipFree(d_pixel); hipFree(d_rgb8);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,136 @@
+"""GPU parity: activation, compositing + loss, compositing gradient (reference nerf.c:7-127)
+through the C ABI launchers against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# pixel colours are sums of <= S products in [0,1]: fp32 reassociation stays below this
+PIX_ATOL = 2e-6
+GRAD_RTOL = 1e-4   # the tolerance the parity contract states for gradients
+GUARD = 1e-4       # rays whose transmittance passes within 1e-4 (relative) of the 0.01 stop are
+                   # excluded from the pixel check: expf differs by an ulp between host and device
+
+
+def random_raw(rng, R, S, dense_frac=0.3):
+    """raw MLP outputs with a mix of empty, thin and opaque rays (opaque ones hit the early stop)"""
+    y = rng.normal(0, 2, size=(R * S, 4)).astype(np.float32)
+    scale = np.where(rng.random(R) < dense_frac, 60.0, 3.0).astype(np.float32)
+    y[:, 0] *= np.repeat(scale, S)
+    return y
+
+
+@pytest.mark.parametrize("R,S", [(16, 128), (5, 128), (3, 64), (7, 100), (4, 1), (9, 2), (2, 256), (1, 1024), (33, 37)])
+def test_launchers_match_oracle(gpu, oracle, R, S):
+    from nerf_amd.api import DeviceArray
+    from nerf_amd._lib import lib
+    rng = np.random.default_rng(R * 1000 + S)
+    y = random_raw(rng, R, S)
+    target = rng.random((R, 3)).astype(np.float32)
+    target_rep = np.repeat(target, S, axis=0)
+
+    d_y = DeviceArray.from_numpy(y)
+    d_dens, d_rgb = DeviceArray((R * S,)), DeviceArray((R * S, 3))
+    lib.activation_kernel_launch(d_y.ptr, d_dens.ptr, d_rgb.ptr, R * S, 4)
+    dens, rgb = d_dens.numpy(), d_rgb.numpy()
+    o_dens, o_rgb = oracle.activation(y)
+    assert np.array_equal(dens, o_dens)                       # ReLU is exact
+    np.testing.assert_allclose(rgb, o_rgb, rtol=0, atol=2e-7)  # sigmoid: expf within an ulp
+
+    # feed the oracle the device's activations so the comparison isolates compositing
+    d_t = DeviceArray.from_numpy(target_rep)
+    d_pix, d_err, d_loss = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray.zeros((1,))
+    lib.volume_rendering_and_loss_launch(d_dens.ptr, d_rgb.ptr, d_t.ptr, d_pix.ptr, d_err.ptr, d_loss.ptr, R, S)
+    pix, err, loss = d_pix.numpy(), d_err.numpy(), float(d_loss.numpy()[0])
+    o_pix, o_err, o_loss, guard = oracle.composite_and_loss(dens, rgb, target_rep, R, S)
+    safe = guard > GUARD
+    assert safe.mean() > 0.8
+    np.testing.assert_allclose(pix[safe], o_pix[safe], rtol=0, atol=PIX_ATOL)
+    np.testing.assert_allclose(err[safe], o_err[safe], rtol=0, atol=PIX_ATOL)
+    # a flipped stop decision changes a pixel by at most the 1% transmittance that is left
+    assert np.abs(pix - o_pix).max() <= 0.0101
+    if safe.all():
+        assert loss == pytest.approx(o_loss, rel=1e-5, abs=1e-6)
+    # loss accumulates (train.c:202 zeroes it first): a second launch doubles it
+    lib.volume_rendering_and_loss_launch(d_dens.ptr, d_rgb.ptr, d_t.ptr, d_pix.ptr, d_err.ptr, d_loss.ptr, R, S)
+    assert float(d_loss.numpy()[0]) == pytest.approx(2 * loss, rel=1e-6)
+
+    # gradient: same err on both sides
+    d_g = DeviceArray((R * S, 4))
+    lib.volume_rendering_gradient_launch(d_dens.ptr, d_rgb.ptr, d_err.ptr, d_g.ptr, R, S)
+    g = d_g.numpy()
+    literal = S <= 128
+    o_g = oracle.composite_gradient(dens, rgb, err, R, S, literal=literal)
+    scale = np.abs(o_g).max() + 1e-30
+    np.testing.assert_allclose(g, o_g, rtol=GRAD_RTOL, atol=1e-6 * scale)
+    assert np.array_equal(g[:, 0] == 0, o_g[:, 0] == 0) or np.abs(g[:, 0] - o_g[:, 0]).max() < 1e-6 * scale
+
+
+def test_early_stop_is_reproduced(gpu, oracle):
+    """An opaque ray stops contributing after transmittance falls below 0.01 in the forward pass
+    (nerf.c:43) but the gradient kernel keeps weighting every sample (nerf.c:82-87)."""
+    from nerf_amd.api import DeviceArray
+    from nerf_amd._lib import lib
+    R, S = 4, 128
+    dens = np.full((R, S), 40.0, np.float32)   # alpha = 0.33 per sample: stop after ~12 samples
+    dens[1] = 0.0                              # empty ray
+    dens[2, 64:] = 0.0
+    dens[3, :] = 1e-3                          # never stops
+    rgb = np.random.default_rng(0).random((R * S, 3)).astype(np.float32)
+    target_rep = np.zeros((R * S, 3), np.float32)
+    d_dens, d_rgb, d_t = DeviceArray.from_numpy(dens.reshape(-1)), DeviceArray.from_numpy(rgb), DeviceArray.from_numpy(target_rep)
+    d_pix, d_err, d_loss = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray.zeros((1,))
+    lib.volume_rendering_and_loss_launch(d_dens.ptr, d_rgb.ptr, d_t.ptr, d_pix.ptr, d_err.ptr, d_loss.ptr, R, S)
+    pix = d_pix.numpy()
+    o_pix, o_err, o_loss, guard = oracle.composite_and_loss(dens.reshape(-1), rgb, target_rep, R, S)
+    assert (guard > 1e-3).all()
+    np.testing.assert_allclose(pix, o_pix, rtol=0, atol=PIX_ATOL)
+    assert np.all(pix[1] == 0)
+    # without the stop the opaque ray's pixel would differ visibly from the stopped one
+    alpha = 1 - np.exp(-dens[0].astype(np.float64) * 0.01)
+    T = np.concatenate([[1.0], np.cumprod(1 - alpha)[:-1]])
+    full = (alpha * T) @ rgb[:S].astype(np.float64)
+    assert np.abs(full - pix[0]).max() > 1e-3
+    d_g = DeviceArray((R * S, 4))
+    lib.volume_rendering_gradient_launch(d_dens.ptr, d_rgb.ptr, d_err.ptr, d_g.ptr, R, S)
+    g = d_g.numpy().reshape(R, S, 4)
+    o_g = oracle.composite_gradient(dens.reshape(-1), rgb, d_err.numpy(), R, S, literal=True).reshape(R, S, 4)
+    np.testing.assert_allclose(g, o_g, rtol=GRAD_RTOL, atol=1e-7)
+    assert np.abs(g[0, 40:, 1:]).max() > 0   # colour gradients continue past the forward stop
+    assert np.all(g[1, :, 0] == 0)            # ReLU derivative at density 0 (nerf.c:123)
+
+
+@pytest.mark.parametrize("R,S", [(16, 128), (6, 256), (5, 77)])
+def test_fused_raw_forms_match_launchers(gpu, R, S):
+    """nerf_composite_forward/backward on the raw MLP output = activation + the two launchers."""
+    from nerf_amd.api import DeviceArray
+    from nerf_amd._lib import lib
+    rng = np.random.default_rng(99 + S)
+    y = random_raw(rng, R, S)
+    target = rng.random((R, 3)).astype(np.float32)
+    d_y, d_t = DeviceArray.from_numpy(y), DeviceArray.from_numpy(target)
+    d_dens, d_rgb = DeviceArray((R * S,)), DeviceArray((R * S, 3))
+    d_pix, d_err, d_loss, d_g = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray.zeros((1,)), DeviceArray((R * S, 4))
+    assert lib.nerf_composite_forward(d_y.ptr, 4, d_t.ptr, 3, d_dens.ptr, d_rgb.ptr, d_pix.ptr, d_err.ptr, R, S) == 0
+    assert lib.nerf_loss_accumulate(d_err.ptr, R, d_loss.ptr) == 0
+    assert lib.nerf_composite_backward(d_y.ptr, 4, d_err.ptr, d_g.ptr, R, S) == 0
+
+    d_dens2, d_rgb2 = DeviceArray((R * S,)), DeviceArray((R * S, 3))
+    lib.activation_kernel_launch(d_y.ptr, d_dens2.ptr, d_rgb2.ptr, R * S, 4)
+    d_trep = DeviceArray.from_numpy(np.repeat(target, S, axis=0))
+    d_pix2, d_err2, d_loss2, d_g2 = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray.zeros((1,)), DeviceArray((R * S, 4))
+    lib.volume_rendering_and_loss_launch(d_dens2.ptr, d_rgb2.ptr, d_trep.ptr, d_pix2.ptr, d_err2.ptr, d_loss2.ptr, R, S)
+    lib.volume_rendering_gradient_launch(d_dens2.ptr, d_rgb2.ptr, d_err2.ptr, d_g2.ptr, R, S)
+    # identical arithmetic on identical inputs: bit-exact
+    assert np.array_equal(d_dens.numpy(), d_dens2.numpy())
+    assert np.array_equal(d_rgb.numpy(), d_rgb2.numpy())
+    assert np.array_equal(d_pix.numpy(), d_pix2.numpy())
+    assert np.array_equal(d_err.numpy(), d_err2.numpy())
+    assert np.array_equal(d_loss.numpy(), d_loss2.numpy())
+    assert np.array_equal(d_g.numpy(), d_g2.numpy())
+
+
+def test_bad_arguments_are_rejected(gpu):
+    from nerf_amd._lib import lib
+    assert lib.nerf_composite_forward(0, 4, 0, 3, 0, 0, 0, 0, 4, 128) == 1
+    assert lib.nerf_composite_backward(0, 4, 0, 0, 4, 128) == 1
