@@ -28,6 +28,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// expf rounded correctly (via the double-precision exp): alpha = 1 - expf(-0.01 * density) cancels
+// for small densities, so a one-ulp difference in expf moves alpha by 6e-8 whatever its size --
+// up to 1e-3 RELATIVE on the weights of a thin medium.  The correctly rounded value is what a host
+// libm returns, and these kernels have the double-precision throughput to spare (HBM-bound).
+__device__ __forceinline__ float expf_cr(float x) { return (float)exp((double)x); }
+
 // exclusive product scan over the 64 lanes of a wavefront
 __device__ __forceinline__ float wave_exclusive_product(float x, int lane) {
     float incl = x;
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void composite_forward_kernel(
                 dens_out[p] = d;
                 rgb_out[p * 3 + 0] = col[i][0]; rgb_out[p * 3 + 1] = col[i][1]; rgb_out[p * 3 + 2] = col[i][2];
             }
-            alpha[i] = 1.0f - expf(-d * NERF_DELTA);  // nerf.c:35
+            alpha[i] = 1.0f - expf_cr(-d * NERF_DELTA);  // nerf.c:35
         }
         local *= (1.0f - alpha[i]);
     }
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
         if (s < S) {
             const size_t p = (size_t)ray * S + s;
             load_sample<RAW>(raw, out_dim, dens_in, rgb_in, p, dens[i], col[i]);
-            alpha[i] = 1.0f - expf(-dens[i] * NERF_DELTA);                     // nerf.c:79
+            alpha[i] = 1.0f - expf_cr(-dens[i] * NERF_DELTA);                  // nerf.c:79
             q[i] = e0 * col[i][0] + e1 * col[i][1] + e2 * col[i][2];            // nerf.c:105-107
         }
         local *= (1.0f - alpha[i]);
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
         const float Rs = a * (aq_next[i] + Rn);
         if (s < S) {
             const float w = alpha[i] * Tbefore[i];                              // nerf.c:86
-            const float da = NERF_DELTA * expf(-dens[i] * NERF_DELTA);         // nerf.c:101
+            const float da = NERF_DELTA * expf_cr(-dens[i] * NERF_DELTA);      // nerf.c:101
             const float gd = da * (Tbefore[i] * q[i] - Rs);
             f32x4 g;
             g[0] = dens[i] > 0.0f ? gd : 0.0f;                                  // nerf.c:123-124

@@ -17,7 +17,8 @@
 // (600 B per point: this kernel is HBM-write bound).
 //
 // Bit-exactness: every IEEE operation of the ray set-up is done in the reference's order with
-// explicit round-to-nearest intrinsics (no FMA contraction), so sample positions and the float
+// FMA contraction switched off (the __f*_rn intrinsics only spell the order out; the correctly
+// rounded sqrtf and '/' are hipcc's defaults), so sample positions and the float
 // arguments of sinf/cosf are bit-identical to a strict C evaluation.  The argument is formed as
 // (float)((double)2^l * M_PI * (double)x), which is what `freq * M_PI * input[i]` means in C
 // (nerf.c:141).  sinf/cosf are the full-range-reduction device functions.
@@ -26,6 +27,9 @@
 #include <string.h>
 #include "../../include/nerf_data.h"
 #include "../../include/nerf_spec.h"
+
+// The bit-exactness contract below needs every a*b+c to stay two roundings, whatever the build flags.
+#pragma clang fp contract(off)
 
 namespace nerf {
 namespace {
@@ -69,7 +73,7 @@ __device__ __forceinline__ void ray_through_pixel(const DeviceCamera& cam, int u
     float y = __fdiv_rn(-__fsub_rn((float)v, __fmul_rn((float)cam.height, 0.5f)), cam.focal);
     float z = -1.0f;
     const float norm =
-        __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
+        sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z)));
     x = __fdiv_rn(x, norm);
     y = __fdiv_rn(y, norm);
     z = __fdiv_rn(z, norm);
@@ -110,10 +114,11 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a) {
             const int img = a.idx[3 * ray + 0], u = a.idx[3 * ray + 1], v = a.idx[3 * ray + 2];
             const DeviceCamera cam = a.cams[img];
             ray_through_pixel(cam, u, v, o, dir);
-            if (a.target && s == 0 && slot < 3) {
+            if (a.target && s == 0 && slot == 0) {
                 // nerf.c:176-179: RGBA pixel, alpha ignored, byte / 255.0f
                 const unsigned char* px = a.pixels + a.img_off[img] + ((size_t)v * cam.width + u) * 4;
-                a.target[ray * 3 + slot] = __fdiv_rn((float)px[slot], 255.0f);
+#pragma unroll
+                for (int c = 0; c < 3; c++) a.target[ray * 3 + c] = __fdiv_rn((float)px[c], 255.0f);
             }
         } else {
             // nerf.c:262-266: render pixel -> dataset-resolution pixel, truncating

@@ -15,6 +15,8 @@
 #include <math.h>
 #include <string.h>
 
+#pragma clang fp contract(off)
+
 namespace nerf {
 namespace {
 
@@ -121,8 +123,9 @@ __global__ __launch_bounds__(256) void skinny_backward_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// AdamW.  Explicit round-to-nearest intrinsics, in the order the CPU statement of the same update
-// would take without FMA contraction, so results are bit-reproducible across host and device.
+// AdamW.  Operations spelled out in the order the CPU statement of the same update takes, with FMA
+// contraction off (file-wide pragma below the includes) and hipcc's correctly rounded sqrtf and '/',
+// so results are bit-reproducible across host and device.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, size_t n,
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
     const float vi = __fadd_rn(__fmul_rn(beta2, v[i]), __fmul_rn(__fmul_rn(c2, gi), gi));
     m[i] = mi;
     v[i] = vi;
-    const float upd = __fdiv_rn(__fmul_rn(alpha_t, mi), __fadd_rn(__fsqrt_rn(vi), eps));
+    const float upd = __fdiv_rn(__fmul_rn(alpha_t, mi), __fadd_rn(sqrtf(vi), eps));
     w[i] = __fsub_rn(__fmul_rn(w[i], decay), upd);
 }
 

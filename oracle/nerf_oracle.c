@@ -20,6 +20,11 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* Ray set-up, sampling, the encoding argument and AdamW must round identically in the strict and
+ * in the fast build (a fused multiply-add in o + t*d moves a position by an ulp, which moves
+ * sin(2^15 pi x) by up to 0.06): these functions never contract, whatever the command line says. */
+#define ORC_NO_CONTRACT __attribute__((optimize("fp-contract=off")))
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
@@ -32,7 +37,7 @@ int orc_num_threads(void) {
  * Rays.  Follows reference data.c:271-290: pinhole camera looking down -z, pixel centre at the
  * integer coordinate, direction normalised BEFORE rotation, rotation rows dotted with (x,y,z).
  * ---------------------------------------------------------------------------------------- */
-void orc_generate_ray(const OrcCamera* cam, int u, int v, float* ray_o, float* ray_d) {
+ORC_NO_CONTRACT void orc_generate_ray(const OrcCamera* cam, int u, int v, float* ray_o, float* ray_d) {
     const float f = cam->focal;
     float cx = ((float)u - (float)cam->width * 0.5f) / f;   /* data.c:273 */
     float cy = -((float)v - (float)cam->height * 0.5f) / f; /* data.c:274 */
@@ -51,8 +56,8 @@ void orc_generate_ray(const OrcCamera* cam, int u, int v, float* ray_o, float* r
 /* Samples.  Follows reference nerf.c:186-198: t = near + (far-near)*s/(S-1), evaluated left to
  * right in float; position = o + t*d; direction copied to every sample.  A per-sample offset
  * (fraction of one bin) is this build's extension; offset 0 is bit-identical to the reference. */
-void orc_sample_ray(const float* ray_o, const float* ray_d, int S, float near_plane, float far_plane,
-                    const float* offsets, float* X) {
+ORC_NO_CONTRACT void orc_sample_ray(const float* ray_o, const float* ray_d, int S, float near_plane,
+                                    float far_plane, const float* offsets, float* X) {
     const float span = far_plane - near_plane;
     const float denom = (float)(S - 1);
     for (int s = 0; s < S; s++) {
@@ -105,7 +110,7 @@ void orc_draw_indices(int num_images, const OrcCamera* cams, int R, int* idx) {
 /* Positional encoding.  Follows reference nerf.c:129-145: identity block, then per octave l and
  * per coordinate i the pair sin, cos of (2^l * pi * x_i).  The product freq * M_PI * x is formed
  * in double (M_PI is a double constant) and narrowed to float at the sinf/cosf call. */
-void orc_positional_encoding(const float* input, int input_dim, int L, float* output) {
+ORC_NO_CONTRACT void orc_positional_encoding(const float* input, int input_dim, int L, float* output) {
     int w = 0;
     for (int i = 0; i < input_dim; i++) output[w++] = input[i];
     for (int l = 0; l < L; l++) {
@@ -520,13 +525,14 @@ void orc_backward_pass_mlp(OrcMLP* m, const float* X, float* grad_X) {
     if (grad_X) mm_nn(m->error_hidden, m->W1, grad_X, B, m->input_dim, m->hidden_dim, m->acc_mode);
 }
 
-void orc_adamw_scalars(float lr, float beta1, float beta2, float wd, int t, float* alpha_t, float* decay) {
+ORC_NO_CONTRACT void orc_adamw_scalars(float lr, float beta1, float beta2, float wd, int t, float* alpha_t,
+                                       float* decay) {
     const float b1t = powf(beta1, (float)t), b2t = powf(beta2, (float)t);
     *alpha_t = lr * sqrtf(1.0f - b2t) / (1.0f - b1t);
     *decay = 1.0f - lr * wd;
 }
 
-static void adamw_apply(float* w, const float* g, float* m, float* v, long n, float inv_unused, float gdiv,
+ORC_NO_CONTRACT static void adamw_apply(float* w, const float* g, float* m, float* v, long n, float inv_unused, float gdiv,
                         float beta1, float beta2, float eps, float alpha_t, float decay) {
     (void)inv_unused;
     const float c1 = 1.0f - beta1, c2 = 1.0f - beta2;
