@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- trained rays/s of the full NeRF training step on N MI355X.
+
+One step = ray generation + sampling + positional encoding, both MLPs forward, compositing + loss,
+compositing gradient, both MLPs backward, (all-reduce of the weight gradients when N > 1), AdamW --
+the loop body of the reference's train.c:169-220 -- on a batch of 4096 rays x 128 samples per GPU
+in fp32, from ray indices and a synthetic 100-view 800x800 dataset already resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured with HIP events around every launch of the
+timed steps (on the stream the kernels run on); `cpu_baseline` times this repo's CPU restatement of
+the same step on the host cores (N = 1 only), as a reported baseline.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# dense fp32 matrix peak and HBM peak of MI355X (spec): 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz; HBM3E
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(seconds=12.0, rays=64, samples=128):
+    """The oracle's fast build (gcc -O3 -fopenmp, blocked products) running the same step."""
+    import numpy as np
+    from oracle.pyoracle import ACC_FAST, Oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import flat_params, make_scene
+
+    orc = Oracle(fast=True)
+    cams, images = make_scene(4, 64, 64)
+    ocams = [orc.camera(*c) for c in cams]
+    pe = 150
+    parts, _ = flat_params(orc, pe, 512, 512, 4)
+    m1 = orc.init_mlp(pe, 512, 512, rays * samples, acc_mode=ACC_FAST)
+    m2 = orc.init_mlp(512, 512, 4, rays * samples, acc_mode=ACC_FAST)
+    a1, a2 = orc.mlp_arrays(m1), orc.mlp_arrays(m2)
+    a1["W1"][:], a1["W2"][:], a2["W1"][:], a2["W2"][:] = parts
+    buf = orc.alloc_step(rays, samples, 16, 8)
+    rng = np.random.default_rng(0)
+
+    def one():
+        idx = np.stack([rng.integers(0, 4, rays), rng.integers(0, 64, rays), rng.integers(0, 64, rays)],
+                       axis=1).astype(np.int32)
+        X, col = orc.batch_from_indices(ocams, images, idx, samples, 2.0, 6.0)
+        orc.forward_backward(m1, m2, buf, X, col, scan_gradient=True)
+        orc.update(m1, 1e-4)
+        orc.update(m2, 1e-4)
+
+    one()  # warm
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    return {
+        "value": rays * n / el,
+        "unit": "rays/s",
+        "cores": orc.num_threads(),
+        "kind": "port",
+        "sample": f"{n} full steps (encode+fwd+bwd+AdamW) of {rays} rays x {samples} samples, fp32, "
+                  f"gcc -O3 -fopenmp blocked products, {el:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import nerf_amd  # noqa: F401  (raises if the HIP library is missing: there is no fallback)
+    from nerf_amd import dp
+    from nerf_amd._lib import lib
+    from nerf_amd.api import DeviceArray, Trainer, prof_read, synthetic_dataset, trainer_config
+
+    torch.cuda.set_device(local_rank)
+    assert lib.nerf_set_device(local_rank) == 0
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    lib.nerf_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    R, S = args.rays, args.samples
+    host = synthetic_dataset(num_images=100, width=800, height=800, seed=1234)  # same scene on every rank
+    dds = host.upload()
+    cfg = trainer_config(rays_per_batch=R, num_samples=S)
+    n_params = int(lib.nerf_trainer_param_count(ctypes.byref(cfg)))
+    params = dp.arena_tensor(n_params, device)
+    grads = dp.arena_tensor(n_params + 4, device)
+    tr = Trainer(cfg, param_arena=params.data_ptr(), grad_arena=grads.data_ptr())
+    tr.init_weights(seed=1, use_rand=False)  # deterministic LCG: identical on every rank
+    dp.broadcast_params(params)
+
+    total_steps = args.warmup + args.steps
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1000 + rank)  # every rank draws its own rays (nerf.c:168-173 order)
+    idx = np.concatenate([host.draw_ray_indices(R) for _ in range(total_steps)], axis=0)
+    d_idx = DeviceArray.from_numpy(idx)  # resident before the timed region
+    idx_stride = R * 3 * 4
+
+    lr_state = {"lr": float(cfg.learning_rate), "t": 0}
+
+    def fwd_bwd_for(step):
+        ptr = d_idx.ptr + step * idx_stride
+        return lambda: nerf_amd.api._check(lib.nerf_trainer_forward_backward(tr.handle, dds.handle, ptr, 0), "fwd/bwd")
+
+    def run_step(step):
+        if world == 1:
+            nerf_amd.api._check(lib.nerf_trainer_step(tr.handle, dds.handle, d_idx.ptr + step * idx_stride, 0), "step")
+        else:
+            if lr_state["t"] % 10000 == 0:  # train.c:171-173
+                lr_state["lr"] = float(np.float32(lr_state["lr"]) * np.float32(0.99))
+            lr_state["t"] += 1
+            dp.DataParallelStep(fwd_bwd_for(step), tr.update, grads, R * S).step(lr_state["lr"])
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        run_step(s)
+    fence()
+    lib.nerf_prof_reset()
+    lib.nerf_prof_enable(1)
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        run_step(s)
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.nerf_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = tr.last_loss()
+
+    if rank == 0:
+        prof = prof_read()
+        kernels = {}
+        for name, (ms, launches, work) in prof.items():
+            if launches == 0:
+                continue
+            entry = {"ms_per_step": ms / args.steps, "launches_per_step": launches / args.steps}
+            if name.startswith("gemm"):
+                entry["tflops"] = work / (ms * 1e-3) / 1e12
+            else:
+                entry["gbs"] = work / (ms * 1e-3) / 1e9
+            kernels[name] = entry
+        gemm = {k: v for k, v in prof.items() if k.startswith("gemm") and v[1] > 0}
+        dom = max(gemm, key=lambda k: gemm[k][0])
+        dms, dlaunch, dwork = gemm[dom]
+        achieved = dwork / (dms * 1e-3) / 1e12
+        all_ms = sum(v[0] for v in gemm.values())
+        all_work = sum(v[2] for v in gemm.values())
+        roofline = {
+            "bound": "mfma",
+            "kernel": f"gemm_f32_kernel ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles)",
+            "achieved": achieved,
+            "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            "avg_launch_ms": dms / dlaunch,
+            "flop_per_launch": dwork / dlaunch,
+            "traffic": None,
+            "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12,
+            "gemm_share_of_step": all_ms / (elapsed * 1e3),
+            "kernels": kernels,
+        }
+        info = nerf_amd.api.device_info()
+        out = {
+            "metric": "trained rays/s @128 samples/ray",
+            "value": world * R * args.steps / elapsed,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "full training step (encode + fwd + composite + bwd + AdamW), "
+                            f"{R} rays x {S} samples per GPU, MLP 150-512-512-512-4, fp32 (BASELINE config 3)",
+                "rays_per_gpu": R,
+                "global_rays": R * world,
+                "samples_per_ray": S,
+                "parallelism": f"dp{world}",
+                "device": info["name"],
+                "compute_units": info["compute_units"],
+            },
+            "final_loss_per_ray": loss,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seconds=args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
