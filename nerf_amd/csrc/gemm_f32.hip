@@ -20,6 +20,7 @@
 #include "common.hpp"
 
 namespace nerf {
+int g_stagger = 1;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,59 +35,78 @@ constexpr int TILE_FLOATS = 128 * KC_LD; // 4608 floats; a KS tile uses the firs
 struct KernelArgs {
     GemmArgs g;
     int tiles_m, tiles_n;
+    int stagger;
 };
 
 // ---- global -> registers -------------------------------------------------------------------
-// A tile covers rows [x0, x0+128) of the non-contracted index (bound X) and contraction steps
-// [k0, k0+32) (bound kend).  Elements outside the bounds read as zero.
+// A tile covers rows [x0, x0+128) of the non-contracted index (bound X) and 32 contraction steps.
+// Loads are raw buffer loads: the per-thread byte offset is fixed for the whole kernel, the K
+// advance is a scalar offset, and everything outside the matrix reads as zero through the
+// hardware range check -- invalid lanes simply carry an out-of-range offset -- so the main loop
+// has no branches and no 64-bit address arithmetic.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned OOR = 0x80000000u;  // >= any num_records used below: reads return 0
+
 template <bool KC, int VEC>
-__device__ __forceinline__ void load_tile(float (&s)[16], const float* __restrict__ base, int ld, int x0, int X,
-                                          int k0, int kend, int tid) {
-    constexpr int PASSES = 16 / VEC;
-    if (KC) {
-        constexpr int TPR = BK / VEC;      // threads per row
-        constexpr int RPP = 256 / TPR;     // rows per pass
-        const int kq = (tid % TPR) * VEC;
-        const int r0 = tid / TPR;
-        const int gk = k0 + kq;
-#pragma unroll
-        for (int p = 0; p < PASSES; p++) {
-            const int row = x0 + r0 + p * RPP;
-            const bool ok = (row < X) && (gk < kend);
-            const float* src = base + (size_t)row * ld + gk;
-            if (VEC == 4) {
-                f32x4 v = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
-                s[p * 4 + 0] = v[0]; s[p * 4 + 1] = v[1]; s[p * 4 + 2] = v[2]; s[p * 4 + 3] = v[3];
-            } else if (VEC == 2) {
-                f32x2 v = ok ? *reinterpret_cast<const f32x2*>(src) : f32x2{0.f, 0.f};
-                s[p * 2 + 0] = v[0]; s[p * 2 + 1] = v[1];
-            } else {
-                s[p] = ok ? *src : 0.f;
-            }
+struct TileLoader {
+    static constexpr int PASSES = 16 / VEC;
+    static constexpr int TPR = (KC ? BK : 128) / VEC;  // threads per LDS row
+    static constexpr int RPP = 256 / TPR;              // LDS rows per pass
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned voff0;       // byte offset of pass 0, or OOR when this thread's column is outside the matrix
+    unsigned pass_stride; // bytes between passes
+    unsigned tile_stride; // bytes per K-tile (scalar offset step)
+    int kfirst;           // contraction index (relative to kbeg) of this thread's pass-0 element
+    int klen;             // kend - kbeg
+
+    __device__ __forceinline__ TileLoader(const float* base, int ld, int x0, int X, int K, int kbeg, int kend,
+                                          int tid) {
+        const int q = (tid % TPR) * VEC;  // position inside the LDS row
+        const int r0 = tid / TPR;         // LDS row of pass 0
+        size_t first, remaining;          // floats: block base, and what is left of the matrix from there
+        if (KC) {  // element (row, k) at row*ld + k
+            first = (size_t)x0 * ld + kbeg;
+            remaining = (size_t)(X - x0 - 1) * ld + (K - kbeg);
+            voff0 = (unsigned)(r0 * ld + q) * 4u;
+            pass_stride = (unsigned)(RPP * ld) * 4u;
+            tile_stride = BK * 4u;
+            kfirst = q;
+        } else {   // element (k, x) at k*ld + x
+            first = (size_t)kbeg * ld + x0;
+            remaining = (size_t)(K - kbeg - 1) * ld + (X - x0);
+            voff0 = (x0 + q < X) ? (unsigned)(r0 * ld + q) * 4u : OOR;
+            pass_stride = (unsigned)(RPP * ld) * 4u;
+            tile_stride = (unsigned)(BK * ld) * 4u;
+            kfirst = r0;
         }
-    } else {
-        constexpr int TPR = 128 / VEC;     // threads per k row
-        constexpr int RPP = 256 / TPR;     // k rows per pass
-        const int xq = (tid % TPR) * VEC;
-        const int kr0 = tid / TPR;
-        const int gx = x0 + xq;
+        const size_t bytes = remaining * 4;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + first), 0,
+                                                 (unsigned)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
+        klen = kend - kbeg;
+    }
+
+    // tile number kt (0-based inside [kbeg, kend)); tiles past the end read as zero
+    __device__ __forceinline__ void load(float (&s)[16], int kt) const {
+        const unsigned soff = (unsigned)kt * tile_stride;
 #pragma unroll
         for (int p = 0; p < PASSES; p++) {
-            const int gk = k0 + kr0 + p * RPP;
-            const bool ok = (gk < kend) && (gx < X);
-            const float* src = base + (size_t)gk * ld + gx;
+            const int k = kt * BK + kfirst + (KC ? 0 : p * RPP);
+            const unsigned off = (k < klen && voff0 != OOR) ? voff0 + (unsigned)p * pass_stride : OOR;
             if (VEC == 4) {
-                f32x4 v = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
+                // (bit_cast the whole vector: element-wise bit_casts of the builtin's result are
+                // narrowed to a single dword load by hipcc 7.2)
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, soff, 0));
                 s[p * 4 + 0] = v[0]; s[p * 4 + 1] = v[1]; s[p * 4 + 2] = v[2]; s[p * 4 + 3] = v[3];
             } else if (VEC == 2) {
-                f32x2 v = ok ? *reinterpret_cast<const f32x2*>(src) : f32x2{0.f, 0.f};
+                const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, soff, 0));
                 s[p * 2 + 0] = v[0]; s[p * 2 + 1] = v[1];
             } else {
-                s[p] = ok ? *src : 0.f;
+                s[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, soff, 0));
             }
         }
     }
-}
+};
 
 // ---- registers -> LDS ----------------------------------------------------------------------
 template <bool KC, int VEC>
@@ -193,43 +213,65 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const KernelArgs ka) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
+    // Two co-resident workgroups (2 waves per SIMD) run the same program; started together they
+    // reach their barriers together and the matrix pipe idles through both gaps.  Holding back the
+    // wave in the odd hardware slot by half a K-tile puts one workgroup's gap under the other's
+    // MFMAs.  Purely a scheduling hint: nothing depends on which waves take it.
+    if (ka.stagger) {
+        unsigned hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        if (hw_id & 1u) __builtin_amdgcn_s_sleep(48);
+    }
+
+    const TileLoader<A_KC, AVEC> la(p.A, p.lda, m0, p.M, p.K, kbeg, kend, tid);
+    const TileLoader<B_KC, BVEC> lb(p.B, p.ldb, n0, p.N, p.K, kbeg, kend, tid);
     float sa[16], sb[16];
     if (nkt > 0) {
-        load_tile<A_KC, AVEC>(sa, p.A, p.lda, m0, p.M, kbeg, kend, tid);
-        load_tile<B_KC, BVEC>(sb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+        la.load(sa, 0);
+        lb.load(sb, 0);
         store_tile<A_KC, AVEC>(lds[0][0], sa, tid);
         store_tile<B_KC, BVEC>(lds[0][1], sb, tid);
+        la.load(sa, 1);
+        lb.load(sb, 1);
     }
     __syncthreads();
 
+    // Per K-tile: 4 groups of 16 MFMAs.  The staged registers of tile kt+1 go to the other LDS buffer
+    // behind group 1, the global loads of tile kt+2 are issued behind group 2, the fragments of
+    // group kk+1 are read while group kk runs: everything but the barrier sits in MFMA shadow.
     for (int kt = 0; kt < nkt; kt++) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            load_tile<A_KC, AVEC>(sa, p.A, p.lda, m0, p.M, k0, kend, tid);
-            load_tile<B_KC, BVEC>(sb, p.B, p.ldb, n0, p.N, k0, kend, tid);
-        }
         const float* TA = lds[cur][0];
         const float* TB = lds[cur][1];
+        float fa[2][2][4], fb[2][2][4];
+        load_frag<A_KC>(fa[0][0], TA, wm * 64, 0, lane);
+        load_frag<A_KC>(fa[0][1], TA, wm * 64 + 32, 0, lane);
+        load_frag<B_KC>(fb[0][0], TB, wn * 64, 0, lane);
+        load_frag<B_KC>(fb[0][1], TB, wn * 64 + 32, 0, lane);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; kk++) {
-            float fa[2][4], fb[2][4];
-            load_frag<A_KC>(fa[0], TA, wm * 64, kk, lane);
-            load_frag<A_KC>(fa[1], TA, wm * 64 + 32, kk, lane);
-            load_frag<B_KC>(fb[0], TB, wn * 64, kk, lane);
-            load_frag<B_KC>(fb[1], TB, wn * 64 + 32, kk, lane);
+            const int c = kk & 1, n = c ^ 1;
+            if (kk + 1 < BK / 8) {
+                load_frag<A_KC>(fa[n][0], TA, wm * 64, kk + 1, lane);
+                load_frag<A_KC>(fa[n][1], TA, wm * 64 + 32, kk + 1, lane);
+                load_frag<B_KC>(fb[n][0], TB, wn * 64, kk + 1, lane);
+                load_frag<B_KC>(fb[n][1], TB, wn * 64 + 32, kk + 1, lane);
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][j], fb[0][j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][j], fb[1][j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][j], fb[0][j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][j], fb[1][j], acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][j], fb[c][0][j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][0][j], fb[c][1][j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][j], fb[c][0][j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][1][j], fb[c][1][j], acc[1][1], 0, 0, 0);
             }
-        }
-        if (more) {
-            store_tile<A_KC, AVEC>(lds[cur ^ 1][0], sa, tid);
-            store_tile<B_KC, BVEC>(lds[cur ^ 1][1], sb, tid);
+            if (kk == 1) {
+                store_tile<A_KC, AVEC>(lds[cur ^ 1][0], sa, tid);
+                store_tile<B_KC, BVEC>(lds[cur ^ 1][1], sb, tid);
+            }
+            if (kk == 2) {
+                la.load(sa, kt + 2);
+                lb.load(sb, kt + 2);
+            }
         }
         __syncthreads();
     }
@@ -244,19 +286,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const KernelArgs ka) {
         for (int ni = 0; ni < 2; ni++) {
             const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
             const int rbase = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
+            const bool col_ok = col < p.N;
+            if (p.epilogue == EPI_DSWISH_MUL) {
+                // all 16 loads first: the stores below may alias them as far as the compiler knows
+                float aux[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < p.M && col < p.N) {
-                    const size_t o = (size_t)row * p.ldc + col;
-                    const float x = acc[mi][ni][r];
-                    if (p.epilogue == EPI_SWISH) {
+                for (int r = 0; r < 16; r++) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    aux[r] = (row < p.M && col_ok) ? p.AUX[(size_t)row * p.ldc + col] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M && col_ok) C[(size_t)row * p.ldc + col] = acc[mi][ni][r] * dswish_f(aux[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M && col_ok) {
+                        const size_t o = (size_t)row * p.ldc + col;
+                        const float x = acc[mi][ni][r];
                         C[o] = x;
-                        p.C2[o] = swish_f(x);
-                    } else if (p.epilogue == EPI_DSWISH_MUL) {
-                        C[o] = x * dswish_f(p.AUX[o]);
-                    } else {
-                        C[o] = x;
+                        if (p.epilogue == EPI_SWISH) p.C2[o] = swish_f(x);
                     }
                 }
             }
@@ -311,6 +363,7 @@ int gemm_f32(const GemmArgs& g) {
     ka.g = g;
     ka.tiles_m = (g.M + BM - 1) / BM;
     ka.tiles_n = (g.N + BN - 1) / BN;
+    ka.stagger = g_stagger;
     long grid = (long)ka.tiles_m * ka.tiles_n;
     if (g.epilogue == EPI_SPLITK) {
         if (g.splits <= 0 || g.k_chunk <= 0 || g.k_chunk % BK != 0) return NERF_ERR_ARG;
@@ -369,3 +422,6 @@ extern "C" size_t nerf_weight_gradient_workspace(int rows_out, int cols, long ba
     const int splits = nerf::choose_splits(tiles, batch, &chunk);
     return (size_t)splits * rows_out * cols * sizeof(float);
 }
+
+// scheduling knob for experiments: 1 = stagger co-resident workgroups (default), 0 = off
+extern "C" void nerf_debug_set_gemm_stagger(int on) { nerf::g_stagger = on; }
