@@ -48,51 +48,56 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOR = 0x80000000u;  // >= any num_records used below: reads return 0
 
-template <bool KC, int VEC>
+template <bool KC, int VEC, bool GUARD_K>
 struct TileLoader {
     static constexpr int PASSES = 16 / VEC;
     static constexpr int TPR = (KC ? BK : 128) / VEC;  // threads per LDS row
     static constexpr int RPP = 256 / TPR;              // LDS rows per pass
     __amdgpu_buffer_rsrc_t rsrc;
-    unsigned voff0;       // byte offset of pass 0, or OOR when this thread's column is outside the matrix
-    unsigned pass_stride; // bytes between passes
-    unsigned tile_stride; // bytes per K-tile (scalar offset step)
-    int kfirst;           // contraction index (relative to kbeg) of this thread's pass-0 element
-    int klen;             // kend - kbeg
+    unsigned voff[PASSES]; // byte offset of each pass, or OOR when this thread's column is outside the matrix
+    unsigned tile_stride;  // bytes per K-tile (scalar offset step)
+    int kfirst;            // contraction index (relative to kbeg) of this thread's pass-0 element
+    int klen;              // kend - kbeg
 
     __device__ __forceinline__ TileLoader(const float* base, int ld, int x0, int X, int K, int kbeg, int kend,
                                           int tid) {
         const int q = (tid % TPR) * VEC;  // position inside the LDS row
         const int r0 = tid / TPR;         // LDS row of pass 0
         size_t first, remaining;          // floats: block base, and what is left of the matrix from there
+        unsigned voff0;
         if (KC) {  // element (row, k) at row*ld + k
             first = (size_t)x0 * ld + kbeg;
             remaining = (size_t)(X - x0 - 1) * ld + (K - kbeg);
             voff0 = (unsigned)(r0 * ld + q) * 4u;
-            pass_stride = (unsigned)(RPP * ld) * 4u;
             tile_stride = BK * 4u;
             kfirst = q;
         } else {   // element (k, x) at k*ld + x
             first = (size_t)kbeg * ld + x0;
             remaining = (size_t)(K - kbeg - 1) * ld + (X - x0);
             voff0 = (x0 + q < X) ? (unsigned)(r0 * ld + q) * 4u : OOR;
-            pass_stride = (unsigned)(RPP * ld) * 4u;
             tile_stride = (unsigned)(BK * ld) * 4u;
             kfirst = r0;
         }
+#pragma unroll
+        for (int p = 0; p < PASSES; p++)
+            voff[p] = voff0 == OOR ? OOR : voff0 + (unsigned)p * (unsigned)(RPP * ld) * 4u;
         const size_t bytes = remaining * 4;
         rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + first), 0,
                                                  (unsigned)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
         klen = kend - kbeg;
     }
 
-    // tile number kt (0-based inside [kbeg, kend)); tiles past the end read as zero
+    // K-tile number kt (0-based inside [kbeg, kend)).  With GUARD_K, contraction steps at or past
+    // kend read as zero; without it the caller guarantees that whole tiles lie inside [kbeg, kend).
     __device__ __forceinline__ void load(float (&s)[16], int kt) const {
         const unsigned soff = (unsigned)kt * tile_stride;
 #pragma unroll
         for (int p = 0; p < PASSES; p++) {
-            const int k = kt * BK + kfirst + (KC ? 0 : p * RPP);
-            const unsigned off = (k < klen && voff0 != OOR) ? voff0 + (unsigned)p * pass_stride : OOR;
+            unsigned off = voff[p];
+            if (GUARD_K) {
+                const int k = kt * BK + kfirst + (KC ? 0 : p * RPP);
+                off = k < klen ? off : OOR;
+            }
             if (VEC == 4) {
                 // (bit_cast the whole vector: element-wise bit_casts of the builtin's result are
                 // narrowed to a single dword load by hipcc 7.2)
@@ -159,13 +164,20 @@ __device__ __forceinline__ void load_frag(float (&frag)[4], const float* __restr
     }
 }
 
-__device__ __forceinline__ float swish_f(float x) { return x / (1.0f + expf(-x)); }
+// sigmoid through the hardware exp2 and reciprocal (about 1 ulp each): the fp32 matrix instruction
+// shares the SIMD's fp32 datapath with ordinary vector instructions, so every VALU instruction of an
+// epilogue is matrix time lost; the IEEE expf + division form costs ~35 instructions per value,
+// this one 4.  Relative error ~3e-7, far inside the 1e-4 parity budget.
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+}
+__device__ __forceinline__ float swish_f(float x) { return x * sigmoid_fast(x); }
 __device__ __forceinline__ float dswish_f(float x) {
-    const float sg = 1.0f / (1.0f + expf(-x));
-    return sg + x * sg * (1.0f - sg);
+    const float sg = sigmoid_fast(x);
+    return sg * (1.0f + x * (1.0f - sg));
 }
 
-template <bool A_KC, bool B_KC, int AVEC, int BVEC>
+template <bool A_KC, bool B_KC, int AVEC, int BVEC, bool GUARD_K>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const KernelArgs ka) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TILE_FLOATS];
     const GemmArgs& p = ka.g;
@@ -223,16 +235,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const KernelArgs ka) {
         if (hw_id & 1u) __builtin_amdgcn_s_sleep(48);
     }
 
-    const TileLoader<A_KC, AVEC> la(p.A, p.lda, m0, p.M, p.K, kbeg, kend, tid);
-    const TileLoader<B_KC, BVEC> lb(p.B, p.ldb, n0, p.N, p.K, kbeg, kend, tid);
+    const TileLoader<A_KC, AVEC, GUARD_K> la(p.A, p.lda, m0, p.M, p.K, kbeg, kend, tid);
+    const TileLoader<B_KC, BVEC, GUARD_K> lb(p.B, p.ldb, n0, p.N, p.K, kbeg, kend, tid);
     float sa[16], sb[16];
     if (nkt > 0) {
         la.load(sa, 0);
         lb.load(sb, 0);
         store_tile<A_KC, AVEC>(lds[0][0], sa, tid);
         store_tile<B_KC, BVEC>(lds[0][1], sb, tid);
-        la.load(sa, 1);
-        lb.load(sb, 1);
+        la.load(sa, nkt > 1 ? 1 : 0);
+        lb.load(sb, nkt > 1 ? 1 : 0);
     }
     __syncthreads();
 
@@ -269,47 +281,68 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const KernelArgs ka) {
                 store_tile<B_KC, BVEC>(lds[cur ^ 1][1], sb, tid);
             }
             if (kk == 2) {
-                la.load(sa, kt + 2);
-                lb.load(sb, kt + 2);
+                // past the last tile the prefetch simply re-reads it (never used): no guard needed
+                const int nt = kt + 2 < nkt ? kt + 2 : nkt - 1;
+                la.load(sa, nt);
+                lb.load(sb, nt);
             }
         }
         __syncthreads();
     }
 
     // Epilogue.  Accumulator register r of a 32x32 tile: column = lane & 31,
-    // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Buffer stores: the per-lane offset is computed once,
+    // the per-register part is a scalar offset, rows past M fall outside the descriptor and columns
+    // past N carry an out-of-range offset -- no per-element address arithmetic or branches.
     float* C = p.C;
     if (p.epilogue == EPI_SPLITK) C += (size_t)split * p.M * p.ldc;
+    const int rows_here = (p.M - m0) < BM ? (p.M - m0) : BM;
+    const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 4u;
+    const __amdgpu_buffer_rsrc_t rC =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(C + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.epilogue == EPI_SWISH ? p.C2 : C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.epilogue == EPI_DSWISH_MUL ? p.AUX : C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+    unsigned voff[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++) {
+    for (int ni = 0; ni < 2; ni++) {
+        const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+        voff[ni] = col < p.N ? (unsigned)((wm * 64 + 4 * (lane >> 5)) * p.ldc + col) * 4u : OOR;
+    }
+    const unsigned row_bytes = (unsigned)p.ldc * 4u;
+    if (p.epilogue == EPI_DSWISH_MUL) {
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
-            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
-            const int rbase = m0 + wm * 64 + mi * 32 + 4 * (lane >> 5);
-            const bool col_ok = col < p.N;
-            if (p.epilogue == EPI_DSWISH_MUL) {
-                // all 16 loads first: the stores below may alias them as far as the compiler knows
+        for (int mi = 0; mi < 2; mi++) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) {
                 float aux[16];
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    aux[r] = (row < p.M && col_ok) ? p.AUX[(size_t)row * p.ldc + col] : 0.f;
+                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
+                    aux[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAUX, voff[ni], soff, 0));
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M && col_ok) C[(size_t)row * p.ldc + col] = acc[mi][ni][r] * dswish_f(aux[r]);
+                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __builtin_bit_cast(unsigned, acc[mi][ni][r] * dswish_f(aux[r])), rC, voff[ni], soff, 0);
                 }
-            } else {
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M && col_ok) {
-                        const size_t o = (size_t)row * p.ldc + col;
-                        const float x = acc[mi][ni][r];
-                        C[o] = x;
-                        if (p.epilogue == EPI_SWISH) p.C2[o] = swish_f(x);
-                    }
+                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
+                    const float x = acc[mi][ni][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rC, voff[ni], soff, 0);
+                    if (p.epilogue == EPI_SWISH)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, swish_f(x)), rC2, voff[ni],
+                                                              soff, 0);
                 }
             }
         }
@@ -336,7 +369,12 @@ int operand_vec(const float* ptr, int ld, int fast_extent) {
 
 template <bool A_KC, bool B_KC, int AVEC, int BVEC>
 void launch(const KernelArgs& ka, int grid) {
-    hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, AVEC, BVEC>), dim3(grid), dim3(256), 0, stream(), ka);
+    // whole K-tiles only (K, and for split-K the chunk, multiples of 32): the loaders need no K guard
+    const bool aligned = ka.g.K % BK == 0 && (ka.g.epilogue != EPI_SPLITK || ka.g.k_chunk % BK == 0);
+    if (aligned)
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, AVEC, BVEC, false>), dim3(grid), dim3(256), 0, stream(), ka);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, AVEC, BVEC, true>), dim3(grid), dim3(256), 0, stream(), ka);
 }
 
 }  // namespace
