@@ -55,10 +55,11 @@ float nerf_event_elapsed_ms(void* start, void* stop);
 int nerf_gemm_f32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, int M,
                   int N, int K, int epilogue, float* C2, const float* AUX);
 /* dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]: split over the batch into slabs
- * in d_workspace (nerf_weight_gradient_workspace bytes), then summed in a fixed order */
+ * in d_workspace (nerf_weight_gradient_workspace bytes), then summed in a fixed order.  Rows of Act
+ * are ld_act >= cols floats apart. */
 size_t nerf_weight_gradient_workspace(int rows_out, int cols, long batch);
-int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, long batch, float* d_dW,
-                         float* d_workspace, int accumulate);
+int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act, long batch,
+                         float* d_dW, float* d_workspace, size_t workspace_bytes, int accumulate);
 
 /* ---- dataset on the device -------------------------------------------------------------------- */
 typedef struct NerfDeviceDataset NerfDeviceDataset;

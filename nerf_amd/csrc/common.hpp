@@ -73,6 +73,7 @@ struct GemmArgs {
     int epilogue;
     int splits;       // EPI_SPLITK: number of contraction chunks (C = slabs base, chunk s at C + s*M*ldc)
     int k_chunk;      // EPI_SPLITK: contraction rows per chunk (multiple of 32)
+    int tile_n;       // EPI_SPLITK: output tile width the caller planned with (128 or 160)
 };
 
 // Enqueues the product; returns NERF_OK or NERF_ERR_ARG (unsupported shape/alignment).
@@ -83,6 +84,11 @@ void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, siz
 
 // Picks the split count for a weight-gradient product with `tiles` output tiles over `rows` points.
 int choose_splits(int tiles, long rows, int* k_chunk);
+// Output tile width of the weight-gradient product for `cols` columns (160 when that pads less).
+int wgrad_tile_n(int cols);
+// Plan of dW[rows_out][cols] += Err^T Act over `batch` points: splits, rows per split, tile width.
+struct WgradPlan { int splits, k_chunk, tile_n; };
+WgradPlan plan_weight_gradient(int rows_out, int cols, long batch);
 
 // ---- skinny (output_dim <= 4) layers -----------------------------------------------------------
 // Y[n][o] = sum_h Hact[n][h] * W2[o][h]

@@ -222,37 +222,36 @@ void adamw_scalars(float lr, float beta1, float beta2, float wd, int t, float* a
     *decay = 1.0f - lr * wd;
 }
 
+WgradPlan plan_weight_gradient(int rows_out, int cols, long batch) {
+    WgradPlan pl;
+    pl.tile_n = wgrad_tile_n(cols);
+    const int tiles = ((rows_out + 127) / 128) * ((cols + pl.tile_n - 1) / pl.tile_n);
+    pl.splits = choose_splits(tiles, batch, &pl.k_chunk);
+    return pl;
+}
+
 size_t mlp_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int batch_size) {
-    size_t need = 0;
-    int chunk = 0;
-    {  // dW1 [hidden][input]
-        const int tiles = ((hidden_dim + 127) / 128) * ((input_dim + 127) / 128);
-        const int splits = choose_splits(tiles, batch_size, &chunk);
-        need = (size_t)splits * hidden_dim * input_dim * sizeof(float);
-    }
-    size_t need2;
-    if (skinny_ok(hidden_dim, output_dim)) {
-        need2 = skinny_backward_workspace(batch_size, hidden_dim, output_dim);
-    } else {
-        const int tiles = ((output_dim + 127) / 128) * ((hidden_dim + 127) / 128);
-        const int splits = choose_splits(tiles, batch_size, &chunk);
-        need2 = (size_t)splits * output_dim * hidden_dim * sizeof(float);
-    }
+    const size_t need = (size_t)plan_weight_gradient(hidden_dim, input_dim, batch_size).splits * hidden_dim *
+                        input_dim * sizeof(float);
+    const size_t need2 = skinny_ok(hidden_dim, output_dim)
+                             ? skinny_backward_workspace(batch_size, hidden_dim, output_dim)
+                             : (size_t)plan_weight_gradient(output_dim, hidden_dim, batch_size).splits * output_dim *
+                                   hidden_dim * sizeof(float);
     return need > need2 ? need : need2;
 }
 
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T * Act[batch][cols]
-void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, long batch, float* dW,
+// Act rows are ld_act floats apart (ld_act >= cols; the trainer pads the 150-wide encoding to 160).
+void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, int ld_act, long batch, float* dW,
                      float* workspace, int accumulate) {
-    const int tiles = ((rows_out + 127) / 128) * ((cols + 127) / 128);
-    int chunk = 0;
-    const int splits = choose_splits(tiles, batch, &chunk);
+    const WgradPlan pl = plan_weight_gradient(rows_out, cols, batch);
+    const int splits = pl.splits;
     GemmArgs g = {};
     g.A = Err; g.lda = rows_out; g.a_kc = 0;
-    g.B = Act; g.ldb = cols; g.b_kc = 0;
+    g.B = Act; g.ldb = ld_act; g.b_kc = 0;
     g.C = workspace; g.ldc = cols;
     g.M = rows_out; g.N = cols; g.K = (int)batch;
-    g.epilogue = EPI_SPLITK; g.splits = splits; g.k_chunk = chunk;
+    g.epilogue = EPI_SPLITK; g.splits = splits; g.k_chunk = pl.k_chunk; g.tile_n = pl.tile_n;
     {
         ProfScope prof(K_GEMM_WGRAD, 2.0 * rows_out * cols * (double)batch);
         if (gemm_f32(g) != NERF_OK) {
@@ -300,8 +299,8 @@ void mlp_backward(MLP* mlp, const float* d_X, float* d_grad_X, int accumulate) {
         skinny_backward(mlp->d_error_output, mlp->d_layer_preact, mlp->d_W2, mlp->d_error_hidden, mlp->d_W2_grad, B,
                         hid, out, mlp->d_workspace, accumulate);
     } else {
-        weight_gradient(mlp->d_error_output, out, mlp->d_layer_postact, hid, B, mlp->d_W2_grad, mlp->d_workspace,
-                        accumulate);
+        weight_gradient(mlp->d_error_output, out, mlp->d_layer_postact, hid, hid, B, mlp->d_W2_grad,
+                        mlp->d_workspace, accumulate);
         GemmArgs g = {};
         g.A = mlp->d_error_output; g.lda = out; g.a_kc = 1;
         g.B = mlp->d_W2; g.ldb = hid; g.b_kc = 0;
@@ -311,7 +310,7 @@ void mlp_backward(MLP* mlp, const float* d_X, float* d_grad_X, int accumulate) {
         ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * out);
         if (gemm_f32(g) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: hidden error failed\n"); exit(EXIT_FAILURE); }
     }
-    weight_gradient(mlp->d_error_hidden, hid, d_X, in, B, mlp->d_W1_grad, mlp->d_workspace, accumulate);
+    weight_gradient(mlp->d_error_hidden, hid, d_X, in, in, B, mlp->d_W1_grad, mlp->d_workspace, accumulate);
     if (d_grad_X) {
         GemmArgs g = {};
         g.A = mlp->d_error_hidden; g.lda = hid; g.a_kc = 1;
@@ -494,9 +493,16 @@ MLP* load_mlp(const char* filename, int custom_batch_size, void* handle) {
 }  // extern "C"
 
 // C-ABI access to the split-K weight-gradient product (declared in include/nerf_amd.h).
-extern "C" int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, long batch,
-                                    float* d_dW, float* d_workspace, int accumulate) {
-    if (!d_err || !d_act || !d_dW || !d_workspace || rows_out <= 0 || cols <= 0 || batch <= 0) return NERF_ERR_ARG;
-    nerf::weight_gradient(d_err, rows_out, d_act, cols, batch, d_dW, d_workspace, accumulate);
+extern "C" size_t nerf_weight_gradient_workspace(int rows_out, int cols, long batch) {
+    return (size_t)nerf::plan_weight_gradient(rows_out, cols, batch).splits * rows_out * cols * sizeof(float);
+}
+
+extern "C" int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act,
+                                    long batch, float* d_dW, float* d_workspace, size_t workspace_bytes,
+                                    int accumulate) {
+    if (!d_err || !d_act || !d_dW || !d_workspace || rows_out <= 0 || cols <= 0 || batch <= 0 || ld_act < cols)
+        return NERF_ERR_ARG;
+    if (workspace_bytes < nerf_weight_gradient_workspace(rows_out, cols, batch)) return NERF_ERR_ARG;
+    nerf::weight_gradient(d_err, rows_out, d_act, cols, ld_act, batch, d_dW, d_workspace, accumulate);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }

@@ -33,6 +33,9 @@ CASES = [
     (128, 128, 4, 1, 0),       # contraction shorter than one K tile
     (1, 1, 1, 1, 1),
     (1024, 256, 1024, 1, 1),
+    (200, 512, 160, 1, 1),     # DMA path, ragged rows
+    (200, 150, 512, 1, 0),     # dense 150-wide output rows (ldc not a multiple of 4)
+    (77, 384, 64, 1, 0),
 ]
 
 
@@ -86,33 +89,42 @@ def test_gemm_is_exact_on_integers(gpu):
     assert np.array_equal(d_C.numpy(), A @ Bm)
 
 
-@pytest.mark.parametrize("rows_out,cols,batch", [(512, 512, 4096), (512, 150, 2048), (512, 150, 1000), (64, 40, 333),
-                                                 (256, 512, 32768), (4, 512, 2048)])
-def test_weight_gradient_split_k(gpu, rows_out, cols, batch):
+@pytest.mark.parametrize("rows_out,cols,ld,batch", [
+    (512, 512, 512, 4096), (512, 150, 150, 2048), (512, 150, 150, 1000), (64, 40, 40, 333),
+    (256, 512, 512, 32768), (4, 512, 512, 2048),
+    (512, 150, 160, 4096),    # padded encoding rows: the 160-wide DMA tile
+    (512, 150, 160, 1000),    # same layout, batch not a multiple of 32: generic path
+    (384, 300, 320, 2048),    # two 160-wide tiles
+    (130, 150, 152, 1024),    # ragged output rows with the wide tile
+])
+def test_weight_gradient_split_k(gpu, rows_out, cols, ld, batch):
     """dW += Err^T Act over a long batch: split-K slabs + fixed-order reduce; accumulate flag."""
     from nerf_amd.api import DeviceArray
     from nerf_amd._lib import lib
     rng = np.random.default_rng(rows_out + cols + batch)
     E = rng.uniform(-1, 1, size=(batch, rows_out)).astype(np.float32)
-    X = rng.uniform(-1, 1, size=(batch, cols)).astype(np.float32)
+    Xp = rng.uniform(-1, 1, size=(batch, ld)).astype(np.float32)   # columns >= cols: padding with junk
+    X = Xp[:, :cols]
     ref = E.astype(np.float64).T @ X.astype(np.float64)
     ws = lib.nerf_weight_gradient_workspace(rows_out, cols, batch)
     d_ws = DeviceArray((ws // 4,))
-    d_E, d_X = DeviceArray.from_numpy(E), DeviceArray.from_numpy(X)
+    d_E, d_X = DeviceArray.from_numpy(E), DeviceArray.from_numpy(Xp)
     base = rng.uniform(-1, 1, size=(rows_out, cols)).astype(np.float32)
     d_dW = DeviceArray.from_numpy(base)
-    assert lib.nerf_weight_gradient(d_E.ptr, rows_out, d_X.ptr, cols, batch, d_dW.ptr, d_ws.ptr, 0) == 0
+    assert lib.nerf_weight_gradient(d_E.ptr, rows_out, d_X.ptr, cols, ld, batch, d_dW.ptr, d_ws.ptr, ws, 0) == 0
     out0 = d_dW.numpy()
     # norm-relative tolerance: fp32 accumulation over `batch` terms
     tol = 3e-7 * np.sqrt(batch) * 4
     assert np.abs(out0 - ref).max() <= tol * (np.abs(ref).max() + 1)
     d_dW.upload(base)
-    assert lib.nerf_weight_gradient(d_E.ptr, rows_out, d_X.ptr, cols, batch, d_dW.ptr, d_ws.ptr, 1) == 0
+    assert lib.nerf_weight_gradient(d_E.ptr, rows_out, d_X.ptr, cols, ld, batch, d_dW.ptr, d_ws.ptr, ws, 1) == 0
     out1 = d_dW.numpy()
     np.testing.assert_allclose(out1, out0 + base, rtol=0, atol=1e-6 * (np.abs(out0).max() + 1))
+    # a workspace that is too small is refused, not overrun
+    assert lib.nerf_weight_gradient(d_E.ptr, rows_out, d_X.ptr, cols, ld, batch, d_dW.ptr, d_ws.ptr, ws - 4, 0) == 1
     # reproducible: the reduce has a fixed order
     d_dW2 = DeviceArray.zeros((rows_out, cols))
-    assert lib.nerf_weight_gradient(d_E.ptr, rows_out, d_X.ptr, cols, batch, d_dW2.ptr, d_ws.ptr, 0) == 0
+    assert lib.nerf_weight_gradient(d_E.ptr, rows_out, d_X.ptr, cols, ld, batch, d_dW2.ptr, d_ws.ptr, ws, 0) == 0
     assert np.array_equal(d_dW2.numpy(), out0)
 
 
