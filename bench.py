@@ -186,7 +186,7 @@ def main():
         all_work = sum(v[2] for v in gemm.values())
         roofline = {
             "bound": "mfma",
-            "kernel": f"gemm_f32_kernel ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles)",
+            "kernel": f"gemm_dma_kernel ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles, LDS-DMA staged)",
             "achieved": achieved,
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",

@@ -151,6 +151,9 @@ int nerf_trainer_steps_done(const NerfTrainer* tr);
 /* device buffers of the last step, for checking: 0 encoding [N][pe], 1 raw output [N][out],
  * 2 pixel [R][3], 3 pixel error [R][3], 4 target [R][3], 5 dLoss/d(raw output) [N][out] */
 const float* nerf_trainer_buffer(NerfTrainer* tr, int which);
+/* Floats between consecutive rows of buffer 0 (the encoding): the encoding width rounded up to a
+ * multiple of 32 (150 -> 160); the tail of every row is zero. */
+int nerf_trainer_encoding_pitch(const NerfTrainer* tr);
 
 /* ---- forward-only render (nerf.c:259-316 for a whole view, chunked over rays) ------------------ */
 /* host_rgb8 [render_h*render_w*3] and/or host_pixel [render_h*render_w*3] (either may be NULL) */

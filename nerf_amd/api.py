@@ -260,6 +260,11 @@ class Trainer:
             self.BUF_PE: (self.N, self.pe_dim), self.BUF_RAW: (self.N, out_dim), self.BUF_PIXEL: (self.R, 3),
             self.BUF_ERR: (self.R, 3), self.BUF_TARGET: (self.R, 3), self.BUF_DRAW: (self.N, out_dim),
         }
+        if which == self.BUF_PE:  # pitched rows with a zero tail
+            ld = int(lib.nerf_trainer_encoding_pitch(self.handle))
+            full = device_to_numpy(lib.nerf_trainer_buffer(self.handle, which), (self.N, ld))
+            assert not full[:, self.pe_dim:].any(), "encoding row tails must stay zero"
+            return np.ascontiguousarray(full[:, : self.pe_dim])
         return device_to_numpy(lib.nerf_trainer_buffer(self.handle, which), shapes[which])
 
     def param_slices(self):

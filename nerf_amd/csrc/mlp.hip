@@ -265,12 +265,17 @@ void weight_gradient(const float* Err, int rows_out, const float* Act, int cols,
 }
 
 void mlp_forward(MLP* mlp, const float* d_X) {
+    const PitchedInput in = {d_X, mlp->input_dim, mlp->d_W1};
+    mlp_forward(mlp, in);
+}
+
+void mlp_forward(MLP* mlp, const PitchedInput& in) {
     const long B = mlp->batch_size;
     GemmArgs g = {};
-    g.A = d_X; g.lda = mlp->input_dim; g.a_kc = 1;
-    g.B = mlp->d_W1; g.ldb = mlp->input_dim; g.b_kc = 1;
+    g.A = in.X; g.lda = in.ld; g.a_kc = 1;
+    g.B = in.W1; g.ldb = in.ld; g.b_kc = 1;
     g.C = mlp->d_layer_preact; g.C2 = mlp->d_layer_postact; g.ldc = mlp->hidden_dim;
-    g.M = (int)B; g.N = mlp->hidden_dim; g.K = mlp->input_dim;
+    g.M = (int)B; g.N = mlp->hidden_dim; g.K = in.ld;
     g.epilogue = EPI_SWISH;
     {
         ProfScope prof(K_GEMM_FWD, 2.0 * (double)B * mlp->hidden_dim * mlp->input_dim);
@@ -292,7 +297,7 @@ void mlp_forward(MLP* mlp, const float* d_X) {
 
 // accumulate: 1 = add to the gradient buffers (the reference's contract: zero_gradients_mlp first),
 //             0 = overwrite them (saves the memset when the caller knows they are stale)
-void mlp_backward(MLP* mlp, const float* d_X, float* d_grad_X, int accumulate) {
+void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int accumulate) {
     const long B = mlp->batch_size;
     const int in = mlp->input_dim, hid = mlp->hidden_dim, out = mlp->output_dim;
     if (skinny_ok(hid, out)) {
@@ -310,7 +315,7 @@ void mlp_backward(MLP* mlp, const float* d_X, float* d_grad_X, int accumulate) {
         ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * out);
         if (gemm_f32(g) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: hidden error failed\n"); exit(EXIT_FAILURE); }
     }
-    weight_gradient(mlp->d_error_hidden, hid, d_X, in, in, B, mlp->d_W1_grad, mlp->d_workspace, accumulate);
+    weight_gradient(mlp->d_error_hidden, hid, d_X, in, ld_X, B, mlp->d_W1_grad, mlp->d_workspace, accumulate);
     if (d_grad_X) {
         GemmArgs g = {};
         g.A = mlp->d_error_hidden; g.lda = hid; g.a_kc = 1;
@@ -419,7 +424,7 @@ void zero_gradients_mlp(MLP* mlp) {
 }
 
 void backward_pass_mlp(MLP* mlp, float* d_X, float* d_grad_X) {
-    mlp_backward(mlp, d_X, d_grad_X, 1);
+    mlp_backward(mlp, d_X, mlp->input_dim, d_grad_X, 1);
     NERF_HIP_CHECK(hipGetLastError());
 }
 

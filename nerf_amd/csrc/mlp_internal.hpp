@@ -10,8 +10,17 @@ namespace nerf {
 // buffers and the weight-gradient workspace.
 MLP* mlp_create(int input_dim, int hidden_dim, int output_dim, int batch_size, void* handle, float* W1, float* W2,
                 float* g1, float* g2, float* m1, float* v1, float* m2, float* v2, bool forward_only);
+// The input of layer 1 as the fast matrix path wants it: rows of `ld` floats (ld >= input_dim, the
+// tail of every row zero) and, if ld != input_dim, a copy of W1 with the same pitch and zero tail.
+// The products then run over `ld` contraction steps; the zero tails add exact zeros.
+struct PitchedInput {
+    const float* X;
+    int ld;
+    const float* W1;  // [hidden_dim][ld]
+};
 void mlp_forward(MLP* mlp, const float* d_X);
-// accumulate = 1: add to the gradient buffers; 0: overwrite them
-void mlp_backward(MLP* mlp, const float* d_X, float* d_grad_X, int accumulate);
+void mlp_forward(MLP* mlp, const PitchedInput& in);
+// accumulate = 1: add to the gradient buffers; 0: overwrite them.  ld_X = floats between rows of d_X.
+void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int accumulate);
 
 }  // namespace nerf

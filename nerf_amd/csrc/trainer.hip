@@ -37,7 +37,9 @@ struct NerfTrainer {
     int owns_params, owns_grads;
     MLP* mlp1;
     MLP* mlp2;
-    float* d_pe;      // [N][pe_dim]
+    int pe_ld;        // floats per row of d_pe: pe_dim rounded up to 32 (150 -> 160), tail zero
+    float* d_pe;      // [N][pe_ld]
+    float* d_w1p;     // [H][pe_ld] copy of mlp1.W1 with the same pitch (nullptr when pe_ld == pe_dim)
     float* d_target;  // [R][3]
     float* d_pixel;   // [R][3]
     float* d_err;     // [R][3]
@@ -75,10 +77,24 @@ void fill_rand(float* w, int fan_out, int fan_in) {
         w[i] = (((float)rand() / (float)RAND_MAX) * 2.0f - 1.0f) * scale;
 }
 
+// Layer 1 of mlp1 reads the encoding in rows of pe_ld floats.  Its weight matrix is re-pitched to
+// match at the start of every step (300 KB copy): the parameter arena may be caller-owned memory
+// that a data-parallel broadcast or a checkpoint load rewrites between steps.
+PitchedInput encoded_input(NerfTrainer* tr) {
+    PitchedInput in = {tr->d_pe, tr->pe_ld, tr->mlp1->d_W1};
+    if (tr->d_w1p) {
+        NERF_HIP_CHECK(hipMemcpy2DAsync(tr->d_w1p, (size_t)tr->pe_ld * 4, tr->mlp1->d_W1, (size_t)tr->pe_dim * 4,
+                                        (size_t)tr->pe_dim * 4, tr->cfg.hidden_dim, hipMemcpyDeviceToDevice,
+                                        stream()));
+        in.W1 = tr->d_w1p;
+    }
+    return in;
+}
+
 int after_forward(NerfTrainer* tr) {
     const int R = tr->cfg.rays_per_batch, S = tr->cfg.num_samples;
     float* loss = tr->d_grads + tr->n_params;
-    mlp_forward(tr->mlp1, tr->d_pe);
+    mlp_forward(tr->mlp1, encoded_input(tr));
     mlp_forward(tr->mlp2, tr->mlp1->d_layer_output);
     if (hipMemsetAsync(loss, 0, 4 * sizeof(float), stream()) != hipSuccess) return NERF_ERR_HIP;
     int rc;
@@ -99,8 +115,8 @@ int after_forward(NerfTrainer* tr) {
                                      tr->mlp2->d_error_output, R, S);
     }
     if (rc != NERF_OK) return rc;
-    mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp1->d_error_output, 0);
-    mlp_backward(tr->mlp1, tr->d_pe, nullptr, 0);
+    mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp2->input_dim, tr->mlp1->d_error_output, 0);
+    mlp_backward(tr->mlp1, tr->d_pe, tr->pe_ld, nullptr, 0);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
@@ -151,7 +167,9 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
     if (d_grad_arena) tr->d_grads = d_grad_arena; else { dalloc(&tr->d_grads, tr->n_params + 4); tr->owns_grads = 1; }
     dalloc(&tr->d_m, tr->n_params);
     dalloc(&tr->d_v, tr->n_params);
-    dalloc(&tr->d_pe, (size_t)N * tr->pe_dim);
+    tr->pe_ld = ((tr->pe_dim + 31) / 32) * 32;
+    dalloc(&tr->d_pe, (size_t)N * tr->pe_ld);
+    if (tr->pe_ld != tr->pe_dim) dalloc(&tr->d_w1p, (size_t)H * tr->pe_ld);
     dalloc(&tr->d_target, (size_t)R * 3);
     dalloc(&tr->d_pixel, (size_t)R * 3);
     dalloc(&tr->d_err, (size_t)R * 3);
@@ -165,6 +183,9 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
         ok = tr->mlp1 && tr->mlp2;
     }
     if (!ok) { nerf_trainer_destroy(tr); return nullptr; }
+    // the row tails stay zero for the trainer's lifetime: the encoder writes pe_dim floats per row
+    NERF_HIP_CHECK(hipMemsetAsync(tr->d_pe, 0, (size_t)N * tr->pe_ld * 4, stream()));
+    if (tr->d_w1p) NERF_HIP_CHECK(hipMemsetAsync(tr->d_w1p, 0, (size_t)H * tr->pe_ld * 4, stream()));
     NERF_HIP_CHECK(hipMemsetAsync(tr->d_m, 0, tr->n_params * 4, stream()));
     NERF_HIP_CHECK(hipMemsetAsync(tr->d_v, 0, tr->n_params * 4, stream()));
     NERF_HIP_CHECK(hipMemsetAsync(tr->d_grads, 0, (tr->n_params + 4) * 4, stream()));
@@ -179,7 +200,7 @@ void nerf_trainer_destroy(NerfTrainer* tr) {
     if (tr->mlp2) free_mlp(tr->mlp2);
     if (tr->owns_params) hipFree(tr->d_params);
     if (tr->owns_grads) hipFree(tr->d_grads);
-    hipFree(tr->d_m); hipFree(tr->d_v); hipFree(tr->d_pe);
+    hipFree(tr->d_m); hipFree(tr->d_v); hipFree(tr->d_pe); hipFree(tr->d_w1p);
     hipFree(tr->d_target); hipFree(tr->d_pixel); hipFree(tr->d_err);
     free(tr);
 }
@@ -218,7 +239,7 @@ int nerf_trainer_forward_backward(NerfTrainer* tr, const NerfDeviceDataset* data
     {
         ProfScope prof(K_ENCODE, (double)c.rays_per_batch * c.num_samples * tr->pe_dim * 4.0);
         rc = nerf_encode_batch(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane, c.far_plane,
-                               c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_dim, tr->d_target, nullptr);
+                               c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld, tr->d_target, nullptr);
     }
     if (rc != NERF_OK) return rc;
     return after_forward(tr);
@@ -231,7 +252,7 @@ int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X
     int rc;
     {
         ProfScope prof(K_ENCODE, (double)N * tr->pe_dim * 4.0);
-        rc = nerf_encode_points(d_batch_X, N, c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_dim);
+        rc = nerf_encode_points(d_batch_X, N, c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld);
     }
     if (rc != NERF_OK) return rc;
     if (hipMemcpyAsync(tr->d_target, d_target, (size_t)c.rays_per_batch * 3 * sizeof(float), hipMemcpyDeviceToDevice,
@@ -270,6 +291,8 @@ float nerf_trainer_last_loss(NerfTrainer* tr) {
 float nerf_trainer_learning_rate(const NerfTrainer* tr) { return tr->learning_rate; }
 int nerf_trainer_steps_done(const NerfTrainer* tr) { return tr->mlp1->t; }
 
+int nerf_trainer_encoding_pitch(const NerfTrainer* tr) { return tr->pe_ld; }
+
 const float* nerf_trainer_buffer(NerfTrainer* tr, int which) {
     switch (which) {
         case 0: return tr->d_pe;
@@ -299,23 +322,35 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
     MLP* r2 = mlp_create(mlp2->input_dim, mlp2->hidden_dim, mlp2->output_dim, N, nullptr, mlp2->d_W1, mlp2->d_W2,
                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
-    float *d_pe = nullptr, *d_pixel = nullptr;
+    const int pe_ld = ((pe_dim + 31) / 32) * 32;  // pitched like the trainer's encoding (zero row tails)
+    float *d_pe = nullptr, *d_pixel = nullptr, *d_w1p = nullptr;
     unsigned char* d_rgb8 = nullptr;
     int rc = NERF_OK;
-    if (!r1 || !r2 || hipMalloc((void**)&d_pe, (size_t)N * pe_dim * 4) != hipSuccess ||
+    if (!r1 || !r2 || hipMalloc((void**)&d_pe, (size_t)N * pe_ld * 4) != hipSuccess ||
+        (pe_ld != pe_dim && hipMalloc((void**)&d_w1p, (size_t)mlp1->hidden_dim * pe_ld * 4) != hipSuccess) ||
         hipMalloc((void**)&d_pixel, (size_t)total * 3 * 4) != hipSuccess ||
         hipMalloc((void**)&d_rgb8, (size_t)total * 3) != hipSuccess)
         rc = NERF_ERR_HIP;
+    PitchedInput in = {d_pe, pe_ld, mlp1->d_W1};
+    if (rc == NERF_OK) {
+        NERF_HIP_CHECK(hipMemsetAsync(d_pe, 0, (size_t)N * pe_ld * 4, stream()));
+        if (d_w1p) {
+            NERF_HIP_CHECK(hipMemsetAsync(d_w1p, 0, (size_t)mlp1->hidden_dim * pe_ld * 4, stream()));
+            NERF_HIP_CHECK(hipMemcpy2DAsync(d_w1p, (size_t)pe_ld * 4, mlp1->d_W1, (size_t)pe_dim * 4, (size_t)pe_dim * 4,
+                                            mlp1->hidden_dim, hipMemcpyDeviceToDevice, stream()));
+            in.W1 = d_w1p;
+        }
+    }
     for (int first = 0; rc == NERF_OK && first < total; first += rays_per_chunk) {
         const int count = (total - first) < rays_per_chunk ? (total - first) : rays_per_chunk;
         // a short last chunk still runs the MLPs at the full chunk size; the extra rows are ignored
         {
             ProfScope prof(K_ENCODE, (double)count * num_samples * pe_dim * 4.0);
             rc = nerf_encode_view(cam, render_w, render_h, first, count, num_samples, near_plane, far_plane, pos_enc_l,
-                                  dir_enc_l, d_pe, pe_dim, nullptr);
+                                  dir_enc_l, d_pe, pe_ld, nullptr);
         }
         if (rc != NERF_OK) break;
-        mlp_forward(r1, d_pe);
+        mlp_forward(r1, in);
         mlp_forward(r2, r1->d_layer_output);
         ProfScope prof(K_COMPOSITE_FWD, (double)count * num_samples * 16.0);
         rc = nerf_composite_forward(r2->d_layer_output, r2->output_dim, nullptr, 0, nullptr, nullptr,
@@ -330,7 +365,7 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
     }
     if (r1) free_mlp(r1);
     if (r2) free_mlp(r2);
-    hipFree(d_pe); hipFree(d_pixel); hipFree(d_rgb8);
+    hipFree(d_pe); hipFree(d_pixel); hipFree(d_rgb8); hipFree(d_w1p);
     return rc;
 }
 
