@@ -131,8 +131,16 @@ MLP* nerf_trainer_mlp(NerfTrainer* tr, int which); /* 0: encoding -> intermediat
  * mlp2 (train.c:125-126); use_rand == 0: the same distribution from a 64-bit LCG seeded with `seed`
  * (identical on every rank and every libc) */
 int nerf_trainer_init_weights(NerfTrainer* tr, int use_rand, unsigned long long seed);
+/* the LCG fill on its own, into host memory: matrix number `which` (0..3 = mlp1.W1, mlp1.W2,
+ * mlp2.W1, mlp2.W2) of nerf_trainer_init_weights(tr, 0, seed).  For callers that own their MLPs
+ * (init_mlp) and want the same reproducible start. */
+void nerf_lcg_weights(float* host_w, int fan_out, int fan_in, unsigned long long seed, int which);
 int nerf_trainer_set_params(NerfTrainer* tr, const float* host_params);
 int nerf_trainer_get_params(NerfTrainer* tr, float* host_params);
+/* resume (train.c:91-121): copies weights, AdamW moments and the step count of two MLPs (e.g. from
+ * load_mlp) into the trainer; 1 if their dimensions differ from the trainer's.  The sources stay
+ * the caller's to free. */
+int nerf_trainer_adopt(NerfTrainer* tr, const MLP* mlp1, const MLP* mlp2);
 /* train.c:176-216: draw-free part of one step.  Leaves the SUM over this batch of the weight
  * gradients and of the squared error in the gradient arena. */
 int nerf_trainer_forward_backward(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,

@@ -155,8 +155,10 @@ _SIGS = {
     "nerf_trainer_grads": (VP, [VP]),
     "nerf_trainer_mlp": (C.POINTER(MLP), [VP, C.c_int]),
     "nerf_trainer_init_weights": (C.c_int, [VP, C.c_int, C.c_ulonglong]),
+    "nerf_lcg_weights": (None, [c_float_p, C.c_int, C.c_int, C.c_ulonglong, C.c_int]),
     "nerf_trainer_set_params": (C.c_int, [VP, VP]),
     "nerf_trainer_get_params": (C.c_int, [VP, VP]),
+    "nerf_trainer_adopt": (C.c_int, [VP, C.POINTER(MLP), C.POINTER(MLP)]),
     "nerf_trainer_forward_backward": (C.c_int, [VP, VP, VP, VP]),
     "nerf_trainer_forward_backward_points": (C.c_int, [VP, VP, VP]),
     "nerf_trainer_update": (C.c_int, [VP, C.c_float, C.c_int]),

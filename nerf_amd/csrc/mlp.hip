@@ -473,6 +473,24 @@ MLP* load_mlp(const char* filename, int custom_batch_size, void* handle) {
         return nullptr;
     }
     const int batch = custom_batch_size > 0 ? custom_batch_size : hdr[5];
+    // a damaged header must not turn into a huge allocation: the dimensions have to account for
+    // the file's length exactly
+    if (hdr[2] <= 0 || hdr[3] <= 0 || hdr[4] <= 0 || batch <= 0 || hdr[6] < 0) {
+        printf("Error: %s has a damaged header\n", filename);
+        fclose(f);
+        return nullptr;
+    }
+    {
+        const long long want = (long long)sizeof(hdr) + 3LL * 4 * ((long long)hdr[3] * hdr[2] + (long long)hdr[4] * hdr[3]);
+        fseek(f, 0, SEEK_END);
+        const long long have = ftell(f);
+        fseek(f, (long)sizeof(hdr), SEEK_SET);
+        if (have != want) {
+            printf("Error: %s is %lld bytes, its header describes %lld\n", filename, have, want);
+            fclose(f);
+            return nullptr;
+        }
+    }
     MLP* mlp = mlp_create(hdr[2], hdr[3], hdr[4], batch, handle, nullptr, nullptr, nullptr, nullptr, nullptr,
                           nullptr, nullptr, nullptr, false);
     if (!mlp) { fclose(f); return nullptr; }

@@ -1,0 +1,327 @@
+/*
+ * train_main.c -- NeRF training driver in plain C on top of libnerf_amd.so.
+ *
+ * Two ways through one training step, selected with --path:
+ *
+ *   classic  the reference's loop body call for call (train.c:169-220) through the drop-in entry
+ *            points: host batch + host-visible encoding, one H2D copy, forward x2, activation,
+ *            zero gradients x2, loss = 0, compositing + loss, compositing gradient, backward x2,
+ *            update x2.  What a maintainer's train.c does after swapping the three <<<>>> launches
+ *            for their launchers and cudaMalloc/cudaMemcpy for nerf_device_malloc/nerf_memcpy_*.
+ *   fused    nerf_trainer_step: rays, samples and encoding generated on the device from ray indices;
+ *            only 12 bytes per ray cross PCIe.  Same arithmetic, same rand() order.
+ *
+ * Everything else follows the reference's driver: LR decay every 10000 batches including the first
+ * (train.c:171-173), progress line every 100 batches with loss / rays (train.c:223-229), a test
+ * render every 5000 (train.c:231-235), time-stamped checkpoints at the end (train.c:240-245), and
+ * resuming from two checkpoint files with the dimension check (train.c:91-121).
+ *
+ *   ./train [--data DIR] [--images N] [--rays R] [--samples S] [--batches B] [--path classic|fused]
+ *           [--render-every K] [--log-every K] [--seed X] [--save PREFIX] [model1.bin model2.bin]
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "nerf_amd.h"
+#include "nerf_kernels.h"
+#include "nerf_spec.h"
+
+typedef struct {
+    const char* data_dir;
+    int max_images, rays, samples, batches, fused, render_every, log_every;
+    long seed; /* < 0: srand(time(NULL)) and rand() everywhere, like train.c:13.  >= 0: repeatable run (see main) */
+    const char* save_prefix;
+    const char* resume[2];
+} Options;
+
+static int parse_options(int argc, char** argv, Options* o) {
+    o->data_dir = "./data";
+    o->max_images = 100;
+    o->rays = NERF_DEFAULT_RAYS_PER_BATCH;
+    o->samples = NERF_DEFAULT_NUM_SAMPLES;
+    o->batches = 2000000;
+    o->fused = 1;
+    o->render_every = 5000;
+    o->log_every = 100;
+    o->seed = -1;
+    o->save_prefix = NULL;
+    o->resume[0] = o->resume[1] = NULL;
+    int positional = 0;
+    for (int i = 1; i < argc; i++) {
+        const char* a = argv[i];
+        const char* v = i + 1 < argc ? argv[i + 1] : NULL;
+        if (a[0] == '-' && a[1] == '-') {
+            if (!v) return -1;
+            if (!strcmp(a, "--data")) o->data_dir = v;
+            else if (!strcmp(a, "--images")) o->max_images = atoi(v);
+            else if (!strcmp(a, "--rays")) o->rays = atoi(v);
+            else if (!strcmp(a, "--samples")) o->samples = atoi(v);
+            else if (!strcmp(a, "--batches")) o->batches = atoi(v);
+            else if (!strcmp(a, "--path")) o->fused = strcmp(v, "classic") != 0;
+            else if (!strcmp(a, "--render-every")) o->render_every = atoi(v);
+            else if (!strcmp(a, "--log-every")) o->log_every = atoi(v);
+            else if (!strcmp(a, "--seed")) o->seed = atol(v);
+            else if (!strcmp(a, "--save")) o->save_prefix = v;
+            else return -1;
+            i++;
+        } else if (positional < 2) {
+            o->resume[positional++] = a;
+        } else {
+            return -1;
+        }
+    }
+    if (positional == 1) return -1; /* train.c:127-131: none or both */
+    return 0;
+}
+
+/* the reference's per-step sequence with the library's drop-in symbols */
+typedef struct {
+    float *batch_X, *batch_pe, *batch_colors;                      /* host, train.c:135-137 */
+    float *d_pe, *d_colors_true, *d_dens, *d_rgb, *d_pix, *d_err, *d_loss; /* device, train.c:140-154 */
+} ClassicBuffers;
+
+static void* device_alloc_or_die(size_t bytes) {
+    void* p = nerf_device_malloc(bytes);
+    if (!p) {
+        fprintf(stderr, "device allocation of %zu bytes failed\n", bytes);
+        exit(EXIT_FAILURE);
+    }
+    return p;
+}
+
+static void classic_alloc(ClassicBuffers* b, int rays, int samples, int pe_dim) {
+    const size_t n = (size_t)rays * samples;
+    b->batch_X = (float*)malloc(n * 6 * sizeof(float));
+    b->batch_pe = (float*)malloc(n * pe_dim * sizeof(float));
+    b->batch_colors = (float*)malloc(n * 3 * sizeof(float));
+    b->d_pe = (float*)device_alloc_or_die(n * pe_dim * sizeof(float));
+    b->d_colors_true = (float*)device_alloc_or_die(n * 3 * sizeof(float));
+    b->d_dens = (float*)device_alloc_or_die(n * sizeof(float));
+    b->d_rgb = (float*)device_alloc_or_die(n * 3 * sizeof(float));
+    b->d_pix = (float*)device_alloc_or_die((size_t)rays * 3 * sizeof(float));
+    b->d_err = (float*)device_alloc_or_die((size_t)rays * 3 * sizeof(float));
+    b->d_loss = (float*)device_alloc_or_die(sizeof(float));
+}
+
+static void classic_free(ClassicBuffers* b) {
+    free(b->batch_X); free(b->batch_pe); free(b->batch_colors);
+    nerf_device_free(b->d_pe); nerf_device_free(b->d_colors_true); nerf_device_free(b->d_dens);
+    nerf_device_free(b->d_rgb); nerf_device_free(b->d_pix); nerf_device_free(b->d_err); nerf_device_free(b->d_loss);
+}
+
+static void classic_step(const Options* o, Dataset* ds, MLP* mlp1, MLP* mlp2, ClassicBuffers* b, int pe_dim,
+                         float lr) {
+    const int n = o->rays * o->samples;
+    generate_random_batch(ds, o->rays, o->samples, NERF_DEFAULT_NEAR, NERF_DEFAULT_FAR, b->batch_X, b->batch_colors);
+    batch_positional_encoding(b->batch_X, o->samples, o->rays, b->batch_pe, NERF_DEFAULT_POS_ENC_L,
+                              NERF_DEFAULT_DIR_ENC_L, pe_dim);
+    CHECK_HIP(nerf_memcpy_h2d(b->d_pe, b->batch_pe, (size_t)n * pe_dim * sizeof(float)));
+    CHECK_HIP(nerf_memcpy_h2d(b->d_colors_true, b->batch_colors, (size_t)n * 3 * sizeof(float)));
+    forward_pass_mlp(mlp1, b->d_pe);
+    forward_pass_mlp(mlp2, mlp1->d_layer_output);
+    activation_kernel_launch(mlp2->d_layer_output, b->d_dens, b->d_rgb, n, mlp2->output_dim);
+    zero_gradients_mlp(mlp1);
+    zero_gradients_mlp(mlp2);
+    CHECK_HIP(nerf_memset(b->d_loss, 0, sizeof(float)));
+    volume_rendering_and_loss_launch(b->d_dens, b->d_rgb, b->d_colors_true, b->d_pix, b->d_err, b->d_loss, o->rays,
+                                     o->samples);
+    volume_rendering_gradient_launch(b->d_dens, b->d_rgb, b->d_err, mlp2->d_error_output, o->rays, o->samples);
+    backward_pass_mlp(mlp2, mlp1->d_layer_output, mlp1->d_error_output);
+    backward_pass_mlp(mlp1, b->d_pe, NULL);
+    update_weights_mlp(mlp1, lr);
+    update_weights_mlp(mlp2, lr);
+}
+
+static double seconds_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int main(int argc, char** argv) {
+    Options o;
+    if (parse_options(argc, argv, &o) != 0) {
+        fprintf(stderr, "Usage: %s [options] [model1.bin model2.bin]\n"
+                        "  no model files: start new training; two: continue from them\n"
+                        "  --data DIR --images N --rays R --samples S --batches B --path classic|fused\n"
+                        "  --render-every K --log-every K --seed X --save PREFIX\n", argv[0]);
+        return -1;
+    }
+
+    const int pe_dim = NERF_PE_DIM3(NERF_DEFAULT_POS_ENC_L) + NERF_PE_DIM3(NERF_DEFAULT_DIR_ENC_L);
+    const int hidden = NERF_DEFAULT_HIDDEN_DIM, inter = NERF_DEFAULT_INTERMEDIATE_DIM, out_dim = NERF_DEFAULT_OUTPUT_DIM;
+    const int points = o.rays * o.samples;
+
+    char json_path[600];
+    snprintf(json_path, sizeof(json_path), "%s/transforms.json", o.data_dir);
+    Dataset* ds = load_dataset(json_path, o.data_dir, o.max_images);
+    if (!ds || ds->num_images == 0) {
+        fprintf(stderr, "Failed to load dataset\n");
+        return -1;
+    }
+
+    CHECK_HIP(nerf_set_device(0));
+    char name[256];
+    int cus = 0, khz = 0;
+    size_t mem = 0;
+    CHECK_HIP(nerf_device_info(name, &cus, &khz, &mem));
+    printf("GPU: %s (%d CUs, %.1f GB)\n", name, cus, (double)mem / 1e9);
+    /* train.c:13.  The HIP runtime draws from rand() itself (first allocations, first launches), so
+     * one srand() cannot make a run repeatable.  With --seed the weights come from the library's
+     * own generator and rand() is re-seeded right before every batch's three-draws-per-ray. */
+    srand(o.seed < 0 ? (unsigned)time(NULL) : (unsigned)o.seed);
+
+    /* MLPs: fresh, or resumed with the reference's dimension check */
+    MLP *mlp1 = NULL, *mlp2 = NULL;
+    NerfTrainer* trainer = NULL;
+    NerfDeviceDataset* dds = NULL;
+    if (o.fused) {
+        NerfTrainerConfig cfg;
+        nerf_trainer_default_config(&cfg);
+        cfg.rays_per_batch = o.rays;
+        cfg.num_samples = o.samples;
+        trainer = nerf_trainer_create(&cfg, NULL, NULL);
+        dds = nerf_dataset_upload(ds);
+        if (!trainer || !dds) {
+            fprintf(stderr, "Failed to set up the device trainer\n");
+            return -1;
+        }
+        mlp1 = nerf_trainer_mlp(trainer, 0);
+        mlp2 = nerf_trainer_mlp(trainer, 1);
+    }
+    if (o.resume[0]) {
+        printf("Loading existing models:\n  Model 1: %s\n  Model 2: %s\n", o.resume[0], o.resume[1]);
+        MLP* l1 = load_mlp(o.resume[0], points, NULL);
+        MLP* l2 = load_mlp(o.resume[1], points, NULL);
+        if (!l1 || !l2) {
+            fprintf(stderr, "Failed to load one or both models\n");
+            if (l1) free_mlp(l1);
+            if (l2) free_mlp(l2);
+            return -1;
+        }
+        if (l1->input_dim != pe_dim || l1->output_dim != inter || l2->input_dim != inter || l2->output_dim != out_dim) {
+            fprintf(stderr, "Model dimensions don't match expected architecture\n");
+            fprintf(stderr, "Expected: %d -> %d -> %d -> %d -> %d\n", pe_dim, hidden, inter, hidden, out_dim);
+            fprintf(stderr, "Loaded: %d -> %d -> %d -> %d -> %d\n", l1->input_dim, l1->hidden_dim, l1->output_dim,
+                    l2->hidden_dim, l2->output_dim);
+            free_mlp(l1);
+            free_mlp(l2);
+            return -1;
+        }
+        if (o.fused) {
+            /* move weights, moments and step count into the trainer's arenas */
+            if (nerf_trainer_adopt(trainer, l1, l2) != 0) {
+                fprintf(stderr, "Loaded models do not fit the trainer\n");
+                return -1;
+            }
+            free_mlp(l1);
+            free_mlp(l2);
+        } else {
+            mlp1 = l1;
+            mlp2 = l2;
+        }
+        printf("Successfully loaded both models (continuing from batch %d)\n", mlp1->t);
+    } else if (o.fused) {
+        printf("Starting new training with two-layer NeRF (device-side batches)\n");
+        CHECK_HIP(nerf_trainer_init_weights(trainer, o.seed < 0, (unsigned long long)o.seed));
+    } else {
+        printf("Starting new training with two-layer NeRF\n");
+        mlp1 = init_mlp(pe_dim, hidden, inter, points, NULL);
+        mlp2 = init_mlp(inter, hidden, out_dim, points, NULL);
+        if (!mlp1 || !mlp2) {
+            fprintf(stderr, "Failed to create the MLPs\n");
+            return -1;
+        }
+        if (o.seed >= 0) { /* replace init_mlp's rand() weights by the repeatable ones */
+            MLP* both[2] = {mlp1, mlp2};
+            for (int k = 0; k < 2; k++) {
+                const size_t n1 = (size_t)both[k]->hidden_dim * both[k]->input_dim;
+                const size_t n2 = (size_t)both[k]->output_dim * both[k]->hidden_dim;
+                float* w = (float*)malloc((n1 > n2 ? n1 : n2) * sizeof(float));
+                nerf_lcg_weights(w, both[k]->hidden_dim, both[k]->input_dim, (unsigned long long)o.seed, 2 * k);
+                CHECK_HIP(nerf_memcpy_h2d(both[k]->d_W1, w, n1 * sizeof(float)));
+                nerf_lcg_weights(w, both[k]->output_dim, both[k]->hidden_dim, (unsigned long long)o.seed, 2 * k + 1);
+                CHECK_HIP(nerf_memcpy_h2d(both[k]->d_W2, w, n2 * sizeof(float)));
+                free(w);
+            }
+        }
+    }
+
+    ClassicBuffers cb;
+    memset(&cb, 0, sizeof(cb));
+    int* idx = NULL;
+    int* d_idx = NULL;
+    if (o.fused) {
+        idx = (int*)malloc((size_t)o.rays * 3 * sizeof(int));
+        d_idx = (int*)device_alloc_or_die((size_t)o.rays * 3 * sizeof(int));
+    } else {
+        classic_alloc(&cb, o.rays, o.samples, pe_dim);
+    }
+
+    printf("Starting NeRF training with %d batches...\n", o.batches);
+    printf("Batch size: %d rays, %d samples per ray\n", o.rays, o.samples);
+    printf("Network: %d -> %d -> %d -> %d -> %d\n", pe_dim, hidden, inter, hidden, out_dim);
+    printf("Positional encoding: pos_L=%d, dir_L=%d, total_dim=%d\n", NERF_DEFAULT_POS_ENC_L, NERF_DEFAULT_DIR_ENC_L,
+           pe_dim);
+
+    float lr = NERF_DEFAULT_LR;
+    const int first = mlp1->t;
+    const double t0 = seconds_now();
+    for (int batch = first; batch < first + o.batches; batch++) {
+        if (batch % NERF_LR_DECAY_EVERY == 0) lr *= NERF_LR_DECAY;
+        if (o.seed >= 0) srand((unsigned)(o.seed + 7919L * (batch + 1)));
+        if (o.fused) {
+            nerf_draw_ray_indices(ds, o.rays, idx);
+            CHECK_HIP(nerf_memcpy_h2d(d_idx, idx, (size_t)o.rays * 3 * sizeof(int)));
+            CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx, NULL));
+            CHECK_HIP(nerf_trainer_update(trainer, lr, points));
+        } else {
+            classic_step(&o, ds, mlp1, mlp2, &cb, pe_dim, lr);
+        }
+        if (o.log_every > 0 && (batch + 1) % o.log_every == 0) {
+            float loss;
+            if (o.fused) {
+                loss = nerf_trainer_last_loss(trainer);
+            } else {
+                CHECK_HIP(nerf_memcpy_d2h(&loss, cb.d_loss, sizeof(float)));
+                loss /= (float)o.rays;
+            }
+            const double el = seconds_now() - t0;
+            printf("Batch [%d/%d], Loss: %.6f, LR: %.6f  (%.0f rays/s)\n", batch + 1, first + o.batches, loss, lr,
+                   (double)(batch + 1 - first) * o.rays / el);
+            if (o.render_every > 0 && (batch + 1) % o.render_every == 0)
+                render_test_image(mlp1, mlp2, ds, batch + 1, NULL, o.samples, NERF_DEFAULT_NEAR, NERF_DEFAULT_FAR,
+                                  NERF_DEFAULT_POS_ENC_L, NERF_DEFAULT_DIR_ENC_L, pe_dim, 128, 128);
+        }
+    }
+    CHECK_HIP(nerf_stream_synchronize());
+
+    char file1[300], file2[300];
+    if (o.save_prefix) {
+        snprintf(file1, sizeof(file1), "%s_nerf_model1.bin", o.save_prefix);
+        snprintf(file2, sizeof(file2), "%s_nerf_model2.bin", o.save_prefix);
+    } else {
+        time_t now = time(NULL);
+        strftime(file1, sizeof(file1), "%Y%m%d_%H%M%S_nerf_model1.bin", localtime(&now));
+        strftime(file2, sizeof(file2), "%Y%m%d_%H%M%S_nerf_model2.bin", localtime(&now));
+    }
+    save_mlp(mlp1, file1);
+    save_mlp(mlp2, file2);
+    printf("\nTraining completed! Models saved to: %s and %s\n", file1, file2);
+
+    if (o.fused) {
+        free(idx);
+        nerf_device_free(d_idx);
+        nerf_dataset_release(dds);
+        nerf_trainer_destroy(trainer);
+    } else {
+        classic_free(&cb);
+        free_mlp(mlp1);
+        free_mlp(mlp2);
+    }
+    free_dataset(ds);
+    return 0;
+}

@@ -209,6 +209,10 @@ float* nerf_trainer_params(NerfTrainer* tr) { return tr->d_params; }
 float* nerf_trainer_grads(NerfTrainer* tr) { return tr->d_grads; }
 MLP* nerf_trainer_mlp(NerfTrainer* tr, int which) { return which == 0 ? tr->mlp1 : (which == 1 ? tr->mlp2 : nullptr); }
 
+void nerf_lcg_weights(float* host_w, int fan_out, int fan_in, unsigned long long seed, int which) {
+    fill_lcg(host_w, fan_out, fan_in, seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)which);
+}
+
 int nerf_trainer_init_weights(NerfTrainer* tr, int use_rand, unsigned long long seed) {
     float* h = (float*)malloc(tr->n_params * sizeof(float));
     if (!h) return NERF_ERR_ARG;
@@ -216,7 +220,7 @@ int nerf_trainer_init_weights(NerfTrainer* tr, int use_rand, unsigned long long 
     const int fan_out[4] = {H, M, H, O}, fan_in[4] = {tr->pe_dim, H, M, H};
     for (int i = 0; i < 4; i++) {
         if (use_rand) fill_rand(h + tr->off[i], fan_out[i], fan_in[i]);
-        else fill_lcg(h + tr->off[i], fan_out[i], fan_in[i], seed + 0x9E3779B97F4A7C15ULL * (unsigned long long)i);
+        else nerf_lcg_weights(h + tr->off[i], fan_out[i], fan_in[i], seed, i);
     }
     const int rc = nerf_trainer_set_params(tr, h);
     free(h);
@@ -229,6 +233,30 @@ int nerf_trainer_set_params(NerfTrainer* tr, const float* host_params) {
 
 int nerf_trainer_get_params(NerfTrainer* tr, float* host_params) {
     return nerf_memcpy_d2h(host_params, tr->d_params, tr->n_params * sizeof(float));
+}
+
+int nerf_trainer_adopt(NerfTrainer* tr, const MLP* mlp1, const MLP* mlp2) {
+    if (!tr || !mlp1 || !mlp2) return NERF_ERR_ARG;
+    const MLP* src[2] = {mlp1, mlp2};
+    MLP* dst[2] = {tr->mlp1, tr->mlp2};
+    for (int i = 0; i < 2; i++)
+        if (src[i]->input_dim != dst[i]->input_dim || src[i]->hidden_dim != dst[i]->hidden_dim ||
+            src[i]->output_dim != dst[i]->output_dim)
+            return NERF_ERR_ARG;
+    for (int i = 0; i < 2; i++) {
+        const size_t n1 = (size_t)dst[i]->hidden_dim * dst[i]->input_dim * 4;
+        const size_t n2 = (size_t)dst[i]->output_dim * dst[i]->hidden_dim * 4;
+        const float* from[6] = {src[i]->d_W1, src[i]->d_W2, src[i]->d_W1_m, src[i]->d_W1_v, src[i]->d_W2_m, src[i]->d_W2_v};
+        float* to[6] = {dst[i]->d_W1, dst[i]->d_W2, dst[i]->d_W1_m, dst[i]->d_W1_v, dst[i]->d_W2_m, dst[i]->d_W2_v};
+        const size_t bytes[6] = {n1, n2, n1, n1, n2, n2};
+        for (int k = 0; k < 6; k++)
+            if (hipMemcpyAsync(to[k], from[k], bytes[k], hipMemcpyDeviceToDevice, stream()) != hipSuccess)
+                return NERF_ERR_HIP;
+        dst[i]->t = src[i]->t;
+    }
+    tr->steps = mlp1->t;
+    // the copies read the source MLPs: finish before the caller frees them
+    return hipStreamSynchronize(stream()) == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
 int nerf_trainer_forward_backward(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
