@@ -29,6 +29,31 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
+# logical product -> the kernel instance that carries it at the benchmark's shapes (rocprofv3 names)
+GEMM_KERNEL = {
+    "gemm_fwd": "gemm_dma_kernel<true, true, 2, 2, 2, 2>",
+    "gemm_dgrad": "gemm_dma_kernel<true, false, 2, 2, 2, 2>",
+    "gemm_wgrad": "gemm_dma_kernel<false, false, 2, 2, 2, 2>",
+}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
+    command (profiles/*_pmc_summary.json, written by tools/pmc_summary.py: FETCH_SIZE doubled as
+    gfx950 needs for 16-byte-per-lane reads, WRITE_SIZE as is).  None when no summary is present:
+    counters cannot be read from inside the timed process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        rec = json.load(open(files[-1])).get(kernel)
+        if rec and "hbm_read_bytes" in rec and "hbm_write_bytes" in rec:
+            return rec["hbm_read_bytes"] + rec["hbm_write_bytes"], rec.get("mfma_util")
+    except (OSError, ValueError):
+        pass
+    return None, None
+
 
 def cpu_baseline(seconds=12.0, rays=64, samples=128):
     """The oracle's fast build (gcc -O3 -fopenmp, blocked products) running the same step."""
@@ -57,23 +82,37 @@ def cpu_baseline(seconds=12.0, rays=64, samples=128):
         orc.update(m1, 1e-4)
         orc.update(m2, 1e-4)
 
-    one()  # warm
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        one()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 200:
-            break
-    return {
+    def timed(budget):
+        one()  # warm
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            one()
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget:
+                return n, el
+
+    threads = orc.num_threads()
+    n, el = timed(seconds)
+    out = {
         "value": rays * n / el,
         "unit": "rays/s",
-        "cores": orc.num_threads(),
+        "cores": threads,
         "kind": "port",
         "sample": f"{n} full steps (encode+fwd+bwd+AdamW) of {rays} rays x {samples} samples, fp32, "
                   f"gcc -O3 -fopenmp blocked products, {el:.1f} s",
     }
+    try:  # the reference's host stages are single-threaded: the same port on one core, for scale
+        import ctypes as C
+        gomp = C.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        n1, el1 = timed(min(6.0, seconds))
+        gomp.omp_set_num_threads(threads)
+        out["single_thread_value"] = rays * n1 / el1
+    except OSError:
+        pass
+    return out
 
 
 def main():
@@ -184,16 +223,24 @@ def main():
         achieved = dwork / (dms * 1e-3) / 1e12
         all_ms = sum(v[0] for v in gemm.values())
         all_work = sum(v[2] for v in gemm.values())
+        traffic, mfma_util = pmc_traffic(GEMM_KERNEL[dom])
+        for name, entry in kernels.items():  # the streaming kernels against the HBM peak
+            if "gbs" in entry:
+                entry["frac_of_hbm_peak"] = entry["gbs"] / PEAK_HBM_GBS
         roofline = {
             "bound": "mfma",
-            "kernel": f"gemm_dma_kernel ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles, LDS-DMA staged)",
+            "kernel": f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles, LDS-DMA staged)",
             "achieved": achieved,
             "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_F32_MFMA_TFLOPS,
             "avg_launch_ms": dms / dlaunch,
             "flop_per_launch": dwork / dlaunch,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
+                            "profiles/*_pmc_summary.json)",
+            "mfma_busy_frac_pmc": mfma_util,
+            "step_flop_frac_of_peak": (3465216.0 * R * S) / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12,
             "gemm_share_of_step": all_ms / (elapsed * 1e3),
             "kernels": kernels,

@@ -328,3 +328,15 @@ def test_bundled_scene_of_the_reference_loads(lib):
         assert (cam.width, cam.height) == (800, 800)
         assert abs(cam.focal - 1111.111) < 0.01  # 800 / (2 tan(0.6911112/2))
     lib.free_dataset(ds)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_DATA, "r_99.png")),
+                    reason="reference checkout not present (GPU box)")
+def test_decoder_is_byte_exact_on_every_bundled_image(lib):
+    """all 100 PNGs of the reference's scene, RGBA for RGBA, against PIL"""
+    for i in range(100):
+        path = os.path.join(REF_DATA, f"r_{i}.png")
+        want = np.asarray(PIL_Image.open(path).convert("RGBA"))
+        got = load_rgba(lib, path)
+        assert got is not None and got.shape == want.shape, path
+        assert np.array_equal(got, want), path

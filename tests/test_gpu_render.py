@@ -1,0 +1,114 @@
+"""GPU parity of the forward-only render (reference nerf.c:219-343) against the CPU oracle:
+rays from the rescaled pixel grid, two forward passes, activation, compositing with early stop,
+truncating quantisation to bytes; chunking must not change anything."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import flat_params, make_scene
+
+pytestmark = pytest.mark.gpu
+
+PIX_ATOL = 2e-6
+REL = 1e-4
+
+
+def setup_pair(gpu, oracle, S, hidden=128, inter=64, Lp=6, Ld=3, density_gain=200.0):
+    from oracle.pyoracle import ACC_F64
+    from nerf_amd.api import Trainer, trainer_config
+    tr = Trainer(trainer_config(rays_per_batch=4, num_samples=S, pos_enc_l=Lp, dir_enc_l=Ld, hidden_dim=hidden,
+                                intermediate_dim=inter))
+    parts, _ = flat_params(oracle, tr.pe_dim, hidden, inter, 4, seed=23)
+    parts[3][0] *= density_gain
+    tr.set_params(np.concatenate([p.reshape(-1) for p in parts]))
+    return tr, parts
+
+
+def oracle_render(oracle, parts, cam_tuple, rw, rh, S, Lp, Ld, hidden, inter):
+    from oracle.pyoracle import ACC_F64
+    pos, rot, focal, w, h = cam_tuple
+    ocam = oracle.camera(pos, rot, focal, w, h)
+    idx = np.empty((rw * rh, 3), np.int32)
+    for v in range(rh):
+        for u in range(rw):  # nerf.c:262-263: truncating rescale in float
+            su = int(np.float32(np.float32(u) * np.float32(w)) / np.float32(rw))
+            sv = int(np.float32(np.float32(v) * np.float32(h)) / np.float32(rh))
+            idx[v * rw + u] = (0, su, sv)
+    dummy = np.zeros((h, w, 4), np.uint8)
+    X, _ = oracle.batch_from_indices([ocam], [dummy], idx, S, 2.0, 6.0)
+    R = rw * rh
+    pe = 3 + 6 * Lp + 3 + 6 * Ld
+    m1 = oracle.init_mlp(pe, hidden, inter, R * S, acc_mode=ACC_F64)
+    m2 = oracle.init_mlp(inter, hidden, 4, R * S, acc_mode=ACC_F64)
+    a1, a2 = oracle.mlp_arrays(m1), oracle.mlp_arrays(m2)
+    a1["W1"][:], a1["W2"][:], a2["W1"][:], a2["W2"][:] = parts
+    buf = oracle.alloc_step(R, S, Lp, Ld)
+    pix = oracle.render_rays(m1, m2, buf, X)
+    oracle.free_step(buf)
+    oracle.free_mlp(m1)
+    oracle.free_mlp(m2)
+    return pix.reshape(rh, rw, 3)
+
+
+def check_bytes(rgb8, pix_ref):
+    """bytes equal the oracle's truncation except where the colour sits on a byte boundary"""
+    want = np.floor(np.clip(pix_ref.astype(np.float64), 0, 1) * 255).astype(np.int32)
+    frac = np.clip(pix_ref.astype(np.float64), 0, 1) * 255
+    near_edge = np.abs(frac - np.round(frac)) < 2e-3
+    diff = rgb8.astype(np.int32) - want
+    assert np.all(diff[~near_edge] == 0)
+    assert np.all(np.abs(diff) <= 1)
+
+
+@pytest.mark.parametrize("rw,rh,S,chunk", [(24, 18, 64, 100), (16, 16, 128, 4096), (7, 5, 33, 3)])
+def test_render_view_matches_oracle(gpu, oracle, rw, rh, S, chunk):
+    from nerf_amd.api import make_camera
+    tr, parts = setup_pair(gpu, oracle, S)
+    cams, _ = make_scene(1, 40, 30)
+    rgb8, pix = tr.render_view(make_camera(*cams[0]), rw, rh, rays_per_chunk=chunk)
+    ref = oracle_render(oracle, parts, cams[0], rw, rh, S, 6, 3, 128, 64)
+    assert ref.max() > 0.1 and ref.min() < 0.05  # the field is neither empty nor saturated
+    np.testing.assert_allclose(pix, ref, rtol=REL, atol=PIX_ATOL)
+    check_bytes(rgb8, pix)
+    # chunk size is invisible
+    rgb8_b, pix_b = tr.render_view(make_camera(*cams[0]), rw, rh, rays_per_chunk=rw * rh)
+    assert np.array_equal(pix, pix_b) and np.array_equal(rgb8, rgb8_b)
+
+
+def test_empty_field_renders_black(gpu, oracle):
+    """zero density everywhere: every pixel is exactly black (nerf.c:299-316)"""
+    from nerf_amd.api import make_camera
+    tr, _ = setup_pair(gpu, oracle, 16, density_gain=0.0)
+    cams, _ = make_scene(1, 8, 8)
+    rgb8, pix = tr.render_view(make_camera(*cams[0]), 4, 4)
+    assert np.array_equal(pix, np.zeros_like(pix)) and np.array_equal(rgb8, np.zeros_like(rgb8))  # empty space
+
+
+def test_render_test_image_writes_the_interpolated_view(gpu, oracle, libc, tmp_path):
+    """render_test_image (nerf.c:219-343): camera from generate_interpolated_camera's three rand()
+    draws, file name %06d_sample.png, 8-bit RGB"""
+    from PIL import Image
+    from nerf_amd._lib import Camera, lib
+    from nerf_amd.api import HostDataset, make_camera
+    S = 32
+    tr, _ = setup_pair(gpu, oracle, S)
+    cams, images = make_scene(4, 40, 30)
+    host = HostDataset([make_camera(*c) for c in cams], images)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        libc.srand(99)
+        lib.render_test_image(lib.nerf_trainer_mlp(tr.handle, 0), lib.nerf_trainer_mlp(tr.handle, 1), C.byref(host.struct),
+                              1234, None, S, 2.0, 6.0, 6, 3, tr.pe_dim, 20, 12)
+    finally:
+        os.chdir(cwd)
+    got = np.asarray(Image.open(tmp_path / "001234_sample.png"))
+    assert got.shape == (12, 20, 3)
+    libc.srand(99)
+    novel = Camera()
+    lib.generate_interpolated_camera(C.byref(host.struct), C.byref(novel))
+    rgb8, _ = tr.render_view(novel, 20, 12)
+    assert np.array_equal(got, rgb8)
+    assert (novel.width, novel.height) == (40, 30)
