@@ -221,6 +221,45 @@ __device__ __forceinline__ void dma_frag(float (&frag)[4], const float* __restri
     }
 }
 
+// One K-tile: start the DMA of tile `next` into the other buffer, run the 32 contraction steps of
+// buffer CUR, barrier.  (`next` past the end re-fetches the last tile; it is never read.)
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int CUR>
+__device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 * BK], const DmaLoader<A_KC, WM * MI * 32>& da,
+                                       const DmaLoader<B_KC, WN * NI * 32>& db, f32x16 (&acc)[MI][NI], int next,
+                                       int wave, int wm, int wn, int lane) {
+    constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32, A_TILE = BM_ * BK;
+    da.issue(lds[CUR ^ 1], next, wave);
+    db.issue(lds[CUR ^ 1] + A_TILE, next, wave);
+    const float* TA = lds[CUR];
+    const float* TB = lds[CUR] + A_TILE;
+    float fa[2][MI][4], fb[2][NI][4];
+#pragma unroll
+    for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_>(fa[0][i], TA, wm * MI * 32 + i * 32, 0, lane);
+#pragma unroll
+    for (int i = 0; i < NI; i++) dma_frag<B_KC, BN_>(fb[0][i], TB, wn * NI * 32 + i * 32, 0, lane);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; kk++) {
+        const int c = kk & 1, n = c ^ 1;
+        if (kk + 1 < BK / 8) {
+#pragma unroll
+            for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_>(fa[n][i], TA, wm * MI * 32 + i * 32, kk + 1, lane);
+#pragma unroll
+            for (int i = 0; i < NI; i++) dma_frag<B_KC, BN_>(fb[n][i], TB, wn * NI * 32 + i * 32, kk + 1, lane);
+        }
+        // keep the reads of group kk+1 in front of group kk's MFMAs: left alone, the scheduler
+        // sinks each read to just before its use and the MFMAs wait out a full LDS latency
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                for (int ni = 0; ni < NI; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][mi][j], fb[c][ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+}
+
 template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI>
 __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const KernelArgs ka) {
     constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32;
@@ -228,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const KernelArgs ka) {
     static_assert(WM * WN == 4 && BM_ == 128, "four wavefronts, 128-row tiles");
     __shared__ __attribute__((aligned(16))) float lds[2][A_TILE + B_TILE];
     const GemmArgs& p = ka.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the DMA's LDS address scalar
     const int wm = wave / WN, wn = wave % WN;
     int tm, tn, split;
     decode_block(ka, blockIdx.x, tm, tn, split);
@@ -250,7 +290,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const KernelArgs ka) {
 
     // The DMA of tile kt+1 is issued at the top of tile kt (its buffer was released by the barrier
     // that ended tile kt-1) and has the whole tile to land; __syncthreads() waits for it (vmcnt)
-    // before the barrier.
+    // before the barrier.  The loop is unrolled by two so that the buffer index is a compile-time
+    // constant: every LDS address is then a loop-invariant per-lane register plus an immediate.
     const DmaLoader<A_KC, BM_> da(p.A, p.lda, m0, p.M, p.K, kbeg, tid);
     const DmaLoader<B_KC, BN_> db(p.B, p.ldb, n0, p.N, p.K, kbeg, tid);
     if (nkt > 0) {
@@ -258,40 +299,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const KernelArgs ka) {
         db.issue(lds[0] + A_TILE, 0, wave);
     }
     __syncthreads();
-    for (int kt = 0; kt < nkt; kt++) {
-        const int cur = kt & 1;
-        const int nt = kt + 1 < nkt ? kt + 1 : kt;  // past the end: re-fetch the last tile (never read)
-        da.issue(lds[cur ^ 1], nt, wave);
-        db.issue(lds[cur ^ 1] + A_TILE, nt, wave);
-        const float* TA = lds[cur];
-        const float* TB = lds[cur] + A_TILE;
-        float fa[2][MI][4], fb[2][NI][4];
-#pragma unroll
-        for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_>(fa[0][i], TA, wm * MI * 32 + i * 32, 0, lane);
-#pragma unroll
-        for (int i = 0; i < NI; i++) dma_frag<B_KC, BN_>(fb[0][i], TB, wn * NI * 32 + i * 32, 0, lane);
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; kk++) {
-            const int c = kk & 1, n = c ^ 1;
-            if (kk + 1 < BK / 8) {
-#pragma unroll
-                for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_>(fa[n][i], TA, wm * MI * 32 + i * 32, kk + 1, lane);
-#pragma unroll
-                for (int i = 0; i < NI; i++) dma_frag<B_KC, BN_>(fb[n][i], TB, wn * NI * 32 + i * 32, kk + 1, lane);
-            }
-            // keep the reads of group kk+1 in front of group kk's MFMAs: left alone, the scheduler
-            // sinks each read to just before its use and the MFMAs wait out a full LDS latency
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int mi = 0; mi < MI; mi++)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ni++)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][mi][j], fb[c][ni][j], acc[mi][ni], 0, 0, 0);
-        }
-        __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        k_tile<A_KC, B_KC, WM, WN, MI, NI, 0>(lds, da, db, acc, kt + 1, wave, wm, wn, lane);
+        k_tile<A_KC, B_KC, WM, WN, MI, NI, 1>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, wm, wn, lane);
     }
+    if (kt < nkt) k_tile<A_KC, B_KC, WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, wm, wn, lane);
     epilogue<MI, NI>(p, acc, m0, n0, split, wm * MI * 32, wn * NI * 32, lane);
 }
 
