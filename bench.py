@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on device 0 with the gloo backend: exercises the multi-rank code path "
+                         "on a one-GPU box (RCCL refuses two ranks on one device); the number is meaningless")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -138,16 +141,24 @@ def main():
     import torch
     import torch.distributed as dist
 
+    trace = (lambda m: print(f"[rank {rank}] {m}", file=sys.stderr, flush=True)) if os.environ.get("NERF_BENCH_TRACE") \
+        else (lambda m: None)
+
     import nerf_amd  # noqa: F401  (raises if the HIP library is missing: there is no fallback)
     from nerf_amd import dp
     from nerf_amd._lib import lib
     from nerf_amd.api import DeviceArray, Trainer, prof_read, synthetic_dataset, trainer_config
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     assert lib.nerf_set_device(local_rank) == 0
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     lib.nerf_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     R, S = args.rays, args.samples
@@ -160,6 +171,7 @@ def main():
     tr = Trainer(cfg, param_arena=params.data_ptr(), grad_arena=grads.data_ptr())
     tr.init_weights(seed=1, use_rand=False)  # deterministic LCG: identical on every rank
     dp.broadcast_params(params)
+    trace("weights broadcast")
 
     total_steps = args.warmup + args.steps
     libc = ctypes.CDLL("libc.so.6")
@@ -184,13 +196,17 @@ def main():
             dp.DataParallelStep(fwd_bwd_for(step), tr.update, grads, R * S).step(lr_state["lr"])
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+
     for s in range(args.warmup):
         run_step(s)
+        trace(f"warmup step {s} enqueued")
     fence()
+    trace("warmup done")
     lib.nerf_prof_reset()
     lib.nerf_prof_enable(1)
     t0 = time.perf_counter()
@@ -199,11 +215,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.nerf_prof_enable(0)
+    trace("timed steps done")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = tr.last_loss()
+    loss = tr.last_loss() / world  # the summed squared error is global after the all-reduce; rays are per rank
 
     if rank == 0:
         prof = prof_read()
@@ -258,7 +275,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {
                 "workload": "full training step (encode + fwd + composite + bwd + AdamW), "
                             f"{R} rays x {S} samples per GPU, MLP 150-512-512-512-4, fp32 (BASELINE config 3)",

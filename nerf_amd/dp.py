@@ -14,6 +14,22 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(tensor, group):
+    """gloo moves host memory: a device tensor is staged through the host around the collective"""
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def all_reduce_sum(flat, group=None):
+    """in-place sum over ranks: RCCL on device tensors (backend nccl), gloo on host tensors; a device
+    tensor under gloo (rehearsing several ranks on one GPU) goes through a host copy"""
+    if _host_staged(flat, group):
+        tmp = flat.cpu()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(tmp)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+
+
 def shard_bounds(total_rays, rank, world_size):
     """[begin, end) of this rank's rays; the global batch must split evenly"""
     if total_rays % world_size != 0:
@@ -41,14 +57,19 @@ class DataParallelStep:
     def step(self, lr):
         self.forward_backward()
         if self.world_size > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            all_reduce_sum(self.flat, self.group)
         self.update(lr, self.global_points)
 
 
 def broadcast_params(params, src=0, group=None):
     """make every rank start from rank `src`'s weights (a 1-D tensor, in place)"""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(params, src=src, group=group)
+        if _host_staged(params, group):
+            tmp = params.cpu()
+            dist.broadcast(tmp, src=src, group=group)
+            params.copy_(tmp)
+        else:
+            dist.broadcast(params, src=src, group=group)
 
 
 def arena_tensor(n_floats, device):
