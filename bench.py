@@ -115,6 +115,48 @@ def cpu_baseline(seconds=12.0, rays=64, samples=128):
     return out
 
 
+def render_workload(args, lib, torch):
+    """nerf_render_view on one 800x800 view (640 000 rays x 128 samples, 98.8 TFLOP of products): the
+    whole call, including its buffer allocation and the D2H copy of the image."""
+    import numpy as np
+
+    import nerf_amd
+    from nerf_amd.api import Trainer, prof_read, synthetic_dataset, trainer_config
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "the render workload is single-GPU"
+    host = synthetic_dataset(num_images=2, width=800, height=800, seed=1234)
+    tr = Trainer(trainer_config(rays_per_batch=16, num_samples=args.samples))
+    tr.init_weights(seed=1, use_rand=False)
+    cam = host.cameras[0]
+    W = H = 800
+    for _ in range(max(1, args.warmup)):
+        tr.render_view(cam, W, H, rays_per_chunk=args.rays)
+    torch.cuda.synchronize()
+    lib.nerf_prof_reset()
+    lib.nerf_prof_enable(1)
+    steps = max(1, min(args.steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rgb8, _ = tr.render_view(cam, W, H, rays_per_chunk=args.rays)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    lib.nerf_prof_enable(0)
+    prof = prof_read()
+    ms, launches, work = prof["gemm_fwd"]
+    achieved = work / (ms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "rendered rays/s @128 samples/ray (forward only)", "value": W * H * steps / el, "unit": "rays/s",
+        "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": el / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"forward-only render of one {W}x{H} view, {args.samples} samples/ray, chunks of "
+                               f"{args.rays} rays, MLP 150-512-512-512-4, fp32 (BASELINE config 2)"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<true, true, 2, 2, 2, 2> (forward products)",
+                     "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "gemm_share_of_step": ms / (el * 1e3)},
+        "mean_byte": float(np.mean(rgb8)),
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +164,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
     ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--workload", choices=["train", "render"], default="train",
+                    help="train: the benchmark of record (BASELINE config 3).  render: forward-only render of one "
+                         "800x800 view at 128 samples/ray (BASELINE config 2), N = 1 only, reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on device 0 with the gloo backend: exercises the multi-rank code path "
@@ -160,6 +205,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
     lib.nerf_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+    if args.workload == "render":
+        return render_workload(args, lib, torch)
 
     R, S = args.rays, args.samples
     host = synthetic_dataset(num_images=100, width=800, height=800, seed=1234)  # same scene on every rank

@@ -56,7 +56,7 @@ struct ProfScope {
 // Epilogues:
 enum GemmEpilogue {
     EPI_STORE = 0,        // C[m][n] = acc
-    EPI_SWISH = 1,        // C[m][n] = acc ; C2[m][n] = swish(acc)
+    EPI_SWISH = 1,        // C[m][n] = acc (skipped when C == nullptr) ; C2[m][n] = swish(acc)
     EPI_DSWISH_MUL = 2,   // C[m][n] = acc * swish'(AUX[m][n])
     EPI_SPLITK = 3,       // slab[split][m][n] = partial acc   (reduced by reduce_slabs)
 };

@@ -102,8 +102,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[MI][NI
     const int tile_rows = 128;
     const int rows_here = (p.M - m0) < tile_rows ? (p.M - m0) : tile_rows;
     const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 4u;
-    const __amdgpu_buffer_rsrc_t rC =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(C + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+    // EPI_SWISH with C == nullptr (forward-only MLPs of the renderer: only the activation is wanted):
+    // a descriptor of zero bytes makes the hardware drop every store to C
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(C + (size_t)m0 * p.ldc), 0, C ? panel_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((p.epilogue == EPI_SWISH ? p.C2 : C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(

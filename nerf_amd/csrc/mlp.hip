@@ -356,8 +356,9 @@ MLP* mlp_create(int input_dim, int hidden_dim, int output_dim, int batch_size, v
         dalloc(&mlp->d_W1_m, n1); dalloc(&mlp->d_W1_v, n1);
         dalloc(&mlp->d_W2_m, n2); dalloc(&mlp->d_W2_v, n2);
     }
-    dalloc(&mlp->d_layer_preact, bh); dalloc(&mlp->d_layer_postact, bh); dalloc(&mlp->d_layer_output, bo);
+    dalloc(&mlp->d_layer_postact, bh); dalloc(&mlp->d_layer_output, bo);
     if (!forward_only) {
+        dalloc(&mlp->d_layer_preact, bh);  // only the backward pass reads the pre-activation
         dalloc(&mlp->d_error_hidden, bh); dalloc(&mlp->d_error_output, bo);
         mlp->workspace_bytes = mlp_workspace_bytes(input_dim, hidden_dim, output_dim, batch_size);
         if (ok && hipMalloc((void**)&mlp->d_workspace, mlp->workspace_bytes) != hipSuccess) ok = false;

@@ -112,3 +112,41 @@ def test_render_test_image_writes_the_interpolated_view(gpu, oracle, libc, tmp_p
     rgb8, _ = tr.render_view(novel, 20, 12)
     assert np.array_equal(got, rgb8)
     assert (novel.width, novel.height) == (40, 30)
+
+
+def test_dataset_resolution_render_full_size(gpu, oracle_fast):
+    """BASELINE config 2 at full size: one 800x800 view, 128 samples/ray, 150-512-512-512-4.
+    Size-independent properties (chunking is invisible; repeated renders are bit-identical) plus
+    the oracle on a scattered handful of the 640 000 pixels."""
+    from oracle.pyoracle import ACC_F64
+    from nerf_amd.api import Trainer, make_camera, trainer_config
+    S, Lp, Ld, H, M = 128, 16, 8, 512, 512
+    tr = Trainer(trainer_config(rays_per_batch=16, num_samples=S))
+    parts, _ = flat_params(oracle_fast, tr.pe_dim, H, M, 4, seed=5)
+    parts[3][0] *= 30.0
+    tr.set_params(np.concatenate([p.reshape(-1) for p in parts]))
+    cams, _ = make_scene(1, 800, 800)
+    cam = make_camera(*cams[0])
+    rgb_a, pix_a = tr.render_view(cam, 800, 800, rays_per_chunk=4096)
+    rgb_b, pix_b = tr.render_view(cam, 800, 800, rays_per_chunk=10000)  # 640000 = 64 x 10000: exact chunks
+    rgb_c, pix_c = tr.render_view(cam, 800, 800, rays_per_chunk=7777)   # ragged last chunk
+    assert np.array_equal(pix_a, pix_b) and np.array_equal(pix_a, pix_c)
+    assert np.array_equal(rgb_a, rgb_b) and np.array_equal(rgb_a, rgb_c)
+    assert np.isfinite(pix_a).all() and pix_a.max() > 0.05
+    check_bytes(rgb_a, pix_a)
+
+    rng = np.random.default_rng(4)
+    us, vs = rng.integers(0, 800, 24), rng.integers(0, 800, 24)
+    idx = np.stack([np.zeros(24, np.int32), us, vs], axis=1).astype(np.int32)  # render scale 1: pixel = dataset pixel
+    ocam = oracle_fast.camera(*cams[0])
+    X, _ = oracle_fast.batch_from_indices([ocam], [np.zeros((800, 800, 4), np.uint8)], idx, S, 2.0, 6.0)
+    m1 = oracle_fast.init_mlp(tr.pe_dim, H, M, 24 * S, acc_mode=ACC_F64)
+    m2 = oracle_fast.init_mlp(M, H, 4, 24 * S, acc_mode=ACC_F64)
+    a1, a2 = oracle_fast.mlp_arrays(m1), oracle_fast.mlp_arrays(m2)
+    a1["W1"][:], a1["W2"][:], a2["W1"][:], a2["W2"][:] = parts
+    buf = oracle_fast.alloc_step(24, S, Lp, Ld)
+    ref = oracle_fast.render_rays(m1, m2, buf, X)
+    np.testing.assert_allclose(pix_a[vs, us], ref, rtol=REL, atol=PIX_ATOL)
+    oracle_fast.free_step(buf)
+    oracle_fast.free_mlp(m1)
+    oracle_fast.free_mlp(m2)
