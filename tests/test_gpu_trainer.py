@@ -204,3 +204,54 @@ def test_create_rejects_bad_config(gpu):
     for kw in [dict(rays_per_batch=0), dict(num_samples=1), dict(num_samples=2048), dict(output_dim=3)]:
         cfg = trainer_config(**kw)
         assert not lib.nerf_trainer_create(C.byref(cfg), 0, 0)
+
+
+def test_full_size_step_properties(gpu, oracle_fast):
+    """BASELINE config 3 at full size (4096 rays x 128 samples, 150-512-512-512-4), where the
+    oracle's whole step is too slow to run: additivity over ray shards, reproducibility, and the
+    oracle on a scattered subset of rays (rays are independent in the forward pass)."""
+    from oracle.pyoracle import ACC_F64
+    from nerf_amd.api import DeviceArray, Trainer
+    R, S = 4096, 128
+    full = Pair(gpu, oracle_fast, R, S, n_images=4)       # the oracle side of this Pair is not stepped
+    idx = full.indices(2024)
+    d_idx = DeviceArray.from_numpy(idx)
+    full.tr.forward_backward(full.dds, d_idx)
+    g_full, sse_full = full.tr.get_grads()
+    pix = full.tr.buffer(Trainer.BUF_PIXEL)
+    raw = full.tr.buffer(Trainer.BUF_RAW)
+    full.tr.forward_backward(full.dds, d_idx)
+    g_again, sse_again = full.tr.get_grads()
+    assert sse_again == sse_full and np.array_equal(g_again, g_full)
+
+    # additivity: two half batches (contiguous ray blocks, as the data-parallel path shards them)
+    half = Pair(gpu, oracle_fast, R // 2, S, n_images=4)
+    acc, sse = np.zeros_like(g_full, dtype=np.float64), 0.0
+    for r in range(2):
+        half.tr.forward_backward(half.dds, DeviceArray.from_numpy(idx[r * R // 2:(r + 1) * R // 2]))
+        g, s = half.tr.get_grads()
+        acc += g
+        sse += s
+        assert np.array_equal(half.tr.buffer(Trainer.BUF_PIXEL), pix[r * R // 2:(r + 1) * R // 2])
+    for off, shape in full.tr.param_slices():
+        n = shape[0] * shape[1]
+        norm_close(g_full[off:off + n], acc[off:off + n], 2e-5)
+    assert sse_full == pytest.approx(sse, rel=1e-5)
+
+    # the oracle on 24 of the 4096 rays
+    pick = np.sort(np.random.default_rng(0).choice(R, 24, replace=False))
+    X, col = oracle_fast.batch_from_indices(full.ocams, full.images, idx[pick], S, 2.0, 6.0)
+    m1 = oracle_fast.init_mlp(150, 512, 512, 24 * S, acc_mode=ACC_F64)
+    m2 = oracle_fast.init_mlp(512, 512, 4, 24 * S, acc_mode=ACC_F64)
+    a1, a2 = oracle_fast.mlp_arrays(m1), oracle_fast.mlp_arrays(m2)
+    a1["W1"][:], a1["W2"][:], a2["W1"][:], a2["W2"][:] = full.a1["W1"], full.a1["W2"], full.a2["W1"], full.a2["W2"]
+    buf = oracle_fast.alloc_step(24, S, 16, 8)
+    ref_pix = oracle_fast.render_rays(m1, m2, buf, X)
+    pix_close(pix[pick], ref_pix)
+    rows = (pick[:, None] * S + np.arange(S)[None, :]).reshape(-1)
+    norm_close(raw[rows], a2["layer_output"])
+    oracle_fast.free_step(buf)
+    oracle_fast.free_mlp(m1)
+    oracle_fast.free_mlp(m2)
+    half.tr.destroy()
+    full.tr.destroy()
