@@ -61,6 +61,24 @@ size_t nerf_weight_gradient_workspace(int rows_out, int cols, long batch);
 int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act, long batch,
                          float* d_dW, float* d_workspace, size_t workspace_bytes, int accumulate);
 
+/* ---- the same products with bf16 operands and fp32 accumulation (v_mfma_f32_32x32x16_bf16), for
+ * the reduced-precision configuration; no counterpart in the reference (fp32 cuBLAS only).  bf16
+ * values are passed as their 16-bit patterns. ----------------------------------------------- */
+/* d_dst[r][c] = bf16(d_src[r][c]) (round to nearest even) with rows ld_dst apart and a zero tail;
+ * transpose != 0 writes the transpose ([cols][ld_dst]) */
+int nerf_convert_bf16(const float* d_src, int rows, int cols, int ld_src, unsigned short* d_dst, int ld_dst,
+                      int transpose);
+/* C[M][N] = A[M][K] B[N][K]^T, K-contiguous operands; K a multiple of 64, N of 4, lda/ldb of 8, ldc of 4.
+ * epilogue 0: C = product; 1: C = pre-activation (may be NULL), C2 = swish(C); 2: C = product .* swish'(AUX) */
+int nerf_gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, unsigned short* C, int ldc,
+                      int M, int N, int K, int epilogue, unsigned short* C2, const unsigned short* AUX);
+/* dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols], fp32 result (rows_out, ld_err, ld_act
+ * multiples of 8; columns of Act between cols and ld_act must hold finite values) */
+size_t nerf_weight_gradient_bf16_workspace(int rows_out, int cols, long batch);
+int nerf_weight_gradient_bf16(const unsigned short* d_err, int rows_out, int ld_err, const unsigned short* d_act,
+                              int cols, int ld_act, long batch, float* d_dW, float* d_workspace,
+                              size_t workspace_bytes, int accumulate);
+
 /* ---- dataset on the device -------------------------------------------------------------------- */
 typedef struct NerfDeviceDataset NerfDeviceDataset;
 /* copies every camera and every image's RGBA8 pixels of a Dataset (data.h:25-29) to the device */

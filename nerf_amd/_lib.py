@@ -101,6 +101,11 @@ _SIGS = {
                                 C.c_int, VP, VP]),
     "nerf_weight_gradient_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_long]),
     "nerf_weight_gradient": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_long, VP, VP, C.c_size_t, C.c_int]),
+    "nerf_convert_bf16": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_int]),
+    "nerf_gemm_bf16_nt": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
+    "nerf_weight_gradient_bf16_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_long]),
+    "nerf_weight_gradient_bf16": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_long, VP, VP, C.c_size_t,
+                                            C.c_int]),
     # dataset / encode
     "nerf_dataset_upload": (VP, [C.POINTER(Dataset)]),
     "nerf_dataset_upload_cameras": (VP, [C.POINTER(Dataset)]),

@@ -90,6 +90,26 @@ int wgrad_tile_n(int cols);
 struct WgradPlan { int splits, k_chunk, tile_n; };
 WgradPlan plan_weight_gradient(int rows_out, int cols, long batch);
 
+// ---- bf16 matrix products (bf16 operands in memory, fp32 accumulation) --------------------------
+typedef unsigned short bf16_t;  // storage type of a bf16 value
+struct GemmBf16Args {
+    const bf16_t* A;    // [M][lda], k-contiguous rows (points)
+    const bf16_t* B;    // [N][ldb], k-contiguous rows (output features)
+    bf16_t* C;          // [M][ldc]: product (EPI_STORE, EPI_DSWISH_MUL) or pre-activation (EPI_SWISH; may be null)
+    bf16_t* C2;         // EPI_SWISH: swish of the rounded pre-activation
+    const bf16_t* AUX;  // EPI_DSWISH_MUL: pre-activation [M][ldc]
+    int M, N, K;        // K a multiple of 64, N a multiple of 4
+    int lda, ldb, ldc;  // lda, ldb multiples of 8; ldc a multiple of 4
+    int epilogue;
+};
+int gemm_bf16_nt(const GemmBf16Args& args);
+WgradPlan plan_weight_gradient_bf16(int rows_out, int cols, long batch);
+// dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]; fp32 result; workspace as planned
+int weight_gradient_bf16(const bf16_t* Err, int rows_out, int ld_err, const bf16_t* Act, int cols, int ld_act,
+                         long batch, float* dW, float* workspace, int accumulate);
+// dst = bf16(src) ([rows][cols] -> [rows][ld_dst], zero tail), or its transpose ([cols][ld_dst])
+int convert_to_bf16(const float* src, int rows, int cols, int ld_src, bf16_t* dst, int ld_dst, int transpose);
+
 // ---- skinny (output_dim <= 4) layers -----------------------------------------------------------
 // Y[n][o] = sum_h Hact[n][h] * W2[o][h]
 void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim);

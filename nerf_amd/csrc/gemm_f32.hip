@@ -34,180 +34,13 @@
 namespace nerf {
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+#include "gemm_device.hpp"
 
-constexpr int BK = 32;
-constexpr int KC_LD = BK + 4;          // generic kernel: floats per LDS row of a KC tile (16 B of padding)
-constexpr unsigned OOR = 0x80000000u;  // >= any num_records used below: loads return 0, stores are dropped
-
-struct KernelArgs {
-    GemmArgs g;
-    int tiles_m, tiles_n;
-};
-
-// ---- activations in the epilogue -------------------------------------------------------------
-// sigmoid through the hardware exp2 and reciprocal (about 1 ulp each): the IEEE expf + division
-// form costs ~35 vector instructions per value, this one 4.  Relative error ~3e-7, far inside the
-// 1e-4 parity budget.
-__device__ __forceinline__ float sigmoid_fast(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
-}
-__device__ __forceinline__ float swish_f(float x) { return x * sigmoid_fast(x); }
-__device__ __forceinline__ float dswish_f(float x) {
-    const float sg = sigmoid_fast(x);
-    return sg * (1.0f + x * (1.0f - sg));
-}
-
-// ---- block -> (tile_m, tile_n, split) -----------------------------------------------------------
-// Blocks b and b+8 share an XCD (and its L2): consecutive slots of one XCD walk the tiles that
-// re-read the same operand panel (the n-tiles of one row panel; the tiles of one split).
-__device__ __forceinline__ void decode_block(const KernelArgs& ka, int b, int& tm, int& tn, int& split) {
-    const GemmArgs& p = ka.g;
-    const int ntile = ka.tiles_m * ka.tiles_n;
-    split = 0;
-    if (p.epilogue == EPI_SPLITK) {
-        int tile;
-        if ((p.splits & 7) == 0) {
-            const int slot = b >> 3;
-            tile = slot % ntile;
-            split = (slot / ntile) * 8 + (b & 7);
-        } else {
-            tile = b % ntile;
-            split = b / ntile;
-        }
-        tm = tile / ka.tiles_n;
-        tn = tile % ka.tiles_n;
-    } else if ((ka.tiles_m & 7) == 0) {
-        const int slot = b >> 3;
-        tn = slot % ka.tiles_n;
-        tm = (slot / ka.tiles_n) * 8 + (b & 7);
-    } else {
-        tn = b % ka.tiles_n;
-        tm = b / ka.tiles_n;
-    }
-}
-
-// ---- epilogue -------------------------------------------------------------------------------------
-// Accumulator register r of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-// Buffer stores: the per-lane offset is computed once, the per-register part is a scalar offset,
-// rows past M fall outside the descriptor and columns past N carry an out-of-range offset -- no
-// per-element address arithmetic or branches.
-template <int MI, int NI>
-__device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[MI][NI], int m0, int n0, int split,
-                                         int wrow, int wcol, int lane) {
-    float* C = p.C;
-    if (p.epilogue == EPI_SPLITK) C += (size_t)split * p.M * p.ldc;
-    const int tile_rows = 128;
-    const int rows_here = (p.M - m0) < tile_rows ? (p.M - m0) : tile_rows;
-    const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 4u;
-    // EPI_SWISH with C == nullptr (forward-only MLPs of the renderer: only the activation is wanted):
-    // a descriptor of zero bytes makes the hardware drop every store to C
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(C + (size_t)m0 * p.ldc), 0, C ? panel_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((p.epilogue == EPI_SWISH ? p.C2 : C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((p.epilogue == EPI_DSWISH_MUL ? p.AUX : C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
-    unsigned voff[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ni++) {
-        const int col = n0 + wcol + ni * 32 + (lane & 31);
-        voff[ni] = col < p.N ? (unsigned)((wrow + 4 * (lane >> 5)) * p.ldc + col) * 4u : OOR;
-    }
-    const unsigned row_bytes = (unsigned)p.ldc * 4u;
-    if (p.epilogue == EPI_DSWISH_MUL) {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-                float aux[16];  // all loads first: the stores may alias them as far as the compiler knows
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
-                    aux[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAUX, voff[ni], soff, 0));
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
-                    __builtin_amdgcn_raw_buffer_store_b32(
-                        __builtin_bit_cast(unsigned, acc[mi][ni][r] * dswish_f(aux[r])), rC, voff[ni], soff, 0);
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
-                    const float x = acc[mi][ni][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rC, voff[ni], soff, 0);
-                    if (p.epilogue == EPI_SWISH)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, swish_f(x)), rC2, voff[ni],
-                                                              soff, 0);
-                }
-            }
-        }
-    }
-}
+constexpr int KC_LD = BK + 4;  // generic kernel: floats per LDS row of a KC tile (16 B of padding)
 
 // ================================================================================================
-// Fast path: LDS-DMA operand staging
+// Fast path: LDS-DMA operand staging (DmaLoader: gemm_device.hpp)
 // ================================================================================================
-// buffer_load_dwordx4 ... lds: a wave-instruction writes 64 x 16 B contiguously at a wave-uniform LDS
-// address, so the LDS image is the linear order of the issuing lanes and any swizzle has to be
-// applied to the SOURCE address.  KC tiles are [ROWS][8 chunks of 16 B] with chunk c of row r
-// stored at position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 lane group touches then fall on
-// 16 different bank slots without padding.  KS tiles ([32][ROWS]) need no swizzle.
-template <bool KC, int ROWS>
-struct DmaLoader {
-    static constexpr int SLOTS = ROWS * BK / 4;  // 16-byte pieces per tile
-    static constexpr int PASSES = SLOTS / 256;
-    static_assert(SLOTS % 256 == 0, "tile must split evenly over 256 lanes");
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned voff[PASSES];
-    unsigned tile_stride;
-
-    __device__ __forceinline__ DmaLoader(const float* base, int ld, int x0, int X, int K, int kbeg, int tid) {
-        size_t first, remaining;  // floats: block base, and what is left of the matrix from there
-        if (KC) {                 // element (row, k) at row*ld + k
-            first = (size_t)x0 * ld + kbeg;
-            remaining = (size_t)(X - x0 - 1) * ld + (K - kbeg);
-            tile_stride = BK * 4u;
-        } else {                  // element (k, x) at k*ld + x
-            first = (size_t)kbeg * ld + x0;
-            remaining = (size_t)(K - kbeg - 1) * ld + (X - x0);
-            tile_stride = (unsigned)(BK * ld) * 4u;
-        }
-#pragma unroll
-        for (int p = 0; p < PASSES; p++) {
-            const int L = p * 256 + tid;  // slot of the LDS image this lane fills in pass p
-            if (KC) {
-                const int row = L >> 3, c = (L & 7) ^ ((row >> 1) & 7);
-                voff[p] = (unsigned)(row * ld + c * 4) * 4u;
-            } else {
-                const int krow = L / (ROWS / 4), xq = (L % (ROWS / 4)) * 4;
-                voff[p] = (x0 + xq < X) ? (unsigned)(krow * ld + xq) * 4u : OOR;
-            }
-        }
-        const size_t bytes = remaining * 4;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + first), 0,
-                                                 (unsigned)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
-    }
-
-    __device__ __forceinline__ void issue(float* tile, int kt, int wave) const {
-        const unsigned soff = (unsigned)kt * tile_stride;
-#pragma unroll
-        for (int p = 0; p < PASSES; p++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void*)(tile + (p * 256 + wave * 64) * 4), 16, voff[p], soff, 0, 0);
-    }
-};
-
 // frag[j] feeds MFMA j of the 8-step group kk: lane l holds element (row rb + (l & 31), k = 8kk + 4(l >> 5) + j)
 template <bool KC, int ROWS>
 __device__ __forceinline__ void dma_frag(float (&frag)[4], const float* __restrict__ T, int rb, int kk, int lane) {
