@@ -157,6 +157,67 @@ def render_workload(args, lib, torch):
     }), flush=True)
 
 
+def bf16_workload(args, lib, torch):
+    """BASELINE config 5: a 1 048 576-ray batch x 256 samples per optimizer step, MLP 150-1024-512-1024-4,
+    bf16 operands / fp32 accumulation, run as micro-batches of 8192 rays whose gradients add up in fp32."""
+    import numpy as np
+
+    import nerf_amd
+    from nerf_amd.api import DeviceArray, Trainer, _check, prof_read, synthetic_dataset, trainer_config
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "the bf16 workload is single-GPU"
+    rays_total, S, micro, hidden, inter = 1 << 20, 256, 8192, 1024, 512
+    host = synthetic_dataset(num_images=100, width=800, height=800, seed=1234)
+    dds = host.upload()
+    tr = Trainer(trainer_config(rays_per_batch=micro, num_samples=S, hidden_dim=hidden, intermediate_dim=inter,
+                                precision=1))
+    tr.init_weights(seed=1, use_rand=False)
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1000)
+    idx = host.draw_ray_indices(rays_total)  # one batch of indices, reused by every step: resident before timing
+    d_idx = DeviceArray.from_numpy(idx)
+    n_micro = rays_total // micro
+
+    def step():
+        for m in range(n_micro):
+            ptr = d_idx.ptr + m * micro * 12
+            fn = lib.nerf_trainer_forward_backward if m == 0 else lib.nerf_trainer_forward_backward_add
+            _check(fn(tr.handle, dds.handle, ptr, 0), "forward/backward")
+        tr.update(1e-4, grad_points=rays_total * S)
+
+    steps = max(1, min(args.steps, 3))
+    for _ in range(min(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    lib.nerf_prof_reset()
+    lib.nerf_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    lib.nerf_prof_enable(0)
+    prof = prof_read()
+    gemm = {k: v for k, v in prof.items() if k.startswith("gemm") and v[1] > 0}
+    all_ms = sum(v[0] for v in gemm.values())
+    all_work = sum(v[2] for v in gemm.values())
+    dom = max(gemm, key=lambda k: gemm[k][0])
+    achieved = gemm[dom][2] / (gemm[dom][0] * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "trained rays/s @256 samples/ray, bf16 operands", "value": rays_total * steps / el, "unit": "rays/s",
+        "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": el / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 operands, f32 accumulate",
+        "data": "synthetic",
+        "config": {"workload": f"{rays_total} rays x {S} samples per optimizer step in {n_micro} micro-batches of "
+                               f"{micro} rays, MLP 150-{hidden}-{inter}-{hidden}-4 (BASELINE config 5)"},
+        "final_loss_per_ray": tr.last_loss() * micro / rays_total,
+        "roofline": {"bound": "mfma", "kernel": f"bf16 products ({dom}: v_mfma_f32_32x32x16_bf16)", "achieved": achieved,
+                     "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
+                     "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12, "gemm_share_of_step": all_ms / (el * 1e3),
+                     "kernels": {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in prof.items()
+                                 if v[1] > 0}},
+    }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,9 +225,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
     ap.add_argument("--samples", type=int, default=128)
-    ap.add_argument("--workload", choices=["train", "render"], default="train",
+    ap.add_argument("--workload", choices=["train", "render", "bf16"], default="train",
                     help="train: the benchmark of record (BASELINE config 3).  render: forward-only render of one "
-                         "800x800 view at 128 samples/ray (BASELINE config 2), N = 1 only, reported separately")
+                         "800x800 view at 128 samples/ray (BASELINE config 2), N = 1 only, reported separately.  "
+                         "bf16: 1M rays x 256 samples per step in micro-batches, hidden width 1024, bf16 operands "
+                         "with fp32 accumulation (BASELINE config 5), N = 1 only, reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on device 0 with the gloo backend: exercises the multi-rank code path "
@@ -208,6 +271,8 @@ def main():
 
     if args.workload == "render":
         return render_workload(args, lib, torch)
+    if args.workload == "bf16":
+        return bf16_workload(args, lib, torch)
 
     R, S = args.rays, args.samples
     host = synthetic_dataset(num_images=100, width=800, height=800, seed=1234)  # same scene on every rank

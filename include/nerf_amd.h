@@ -100,6 +100,10 @@ void nerf_draw_ray_indices(const Dataset* dataset, int rays_per_batch, int* idx)
 int nerf_encode_batch(const NerfDeviceDataset* dataset, const int* d_idx, const float* d_offsets, int R, int S,
                       float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe,
                       float* d_target, float* d_batch_X);
+/* nerf_encode_batch writing the encoding as bf16 bit patterns (round to nearest even) */
+int nerf_encode_batch_bf16(const NerfDeviceDataset* dataset, const int* d_idx, const float* d_offsets, int R, int S,
+                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, unsigned short* d_pe,
+                           int ld_pe, float* d_target);
 /* positional_encoding (nerf.c:129-145) of one device vector of any dimension:
  * d_out [dim + 2*dim*L] */
 int nerf_encode_vector(const float* d_in, int dim, int L, float* d_out);
@@ -131,7 +135,12 @@ typedef struct {
     int pos_enc_l, dir_enc_l;                   /* train.c:20-21 */
     int hidden_dim, intermediate_dim, output_dim; /* train.c:42-44 */
     float learning_rate;                        /* train.c:160 */
+    int precision;                              /* NERF_PRECISION_F32 (the reference's arithmetic) or _BF16 */
 } NerfTrainerConfig;
+/* NERF_PRECISION_BF16: activations and the weights as the matrix cores read them are bf16, products
+ * accumulate in fp32, master weights / gradients / AdamW / compositing stay fp32.  Needs hidden and
+ * intermediate widths that are multiples of 64.  No counterpart in the reference. */
+enum { NERF_PRECISION_F32 = 0, NERF_PRECISION_BF16 = 1 };
 
 void nerf_trainer_default_config(NerfTrainerConfig* cfg);
 /* number of weights of the two MLPs: hidden*pe + intermediate*hidden + hidden*intermediate + output*hidden */
@@ -163,7 +172,13 @@ int nerf_trainer_adopt(NerfTrainer* tr, const MLP* mlp1, const MLP* mlp2);
  * gradients and of the squared error in the gradient arena. */
 int nerf_trainer_forward_backward(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
                                   const float* d_offsets);
-/* same with host-chosen samples: d_batch_X [R*S][6] as generate_random_batch builds it, d_target [R][3] */
+/* micro-batching: the same, ADDING this batch's gradient sums and squared error to what the gradient
+ * arena holds.  First micro-batch: nerf_trainer_forward_backward; the others: this; then one
+ * nerf_trainer_update with the total number of points. */
+int nerf_trainer_forward_backward_add(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
+                                      const float* d_offsets);
+/* same with host-chosen samples: d_batch_X [R*S][6] as generate_random_batch builds it, d_target [R][3]
+ * (fp32 precision only) */
 int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X, const float* d_target);
 /* train.c:219-220: AdamW on gradient / grad_points for both MLPs; grad_points is rays*samples of
  * the whole (global) batch, the reference's batch_size */
@@ -180,6 +195,10 @@ const float* nerf_trainer_buffer(NerfTrainer* tr, int which);
 /* Floats between consecutive rows of buffer 0 (the encoding): the encoding width rounded up to a
  * multiple of 32 (150 -> 160); the tail of every row is zero. */
 int nerf_trainer_encoding_pitch(const NerfTrainer* tr);
+/* bf16 precision only: 16-bit buffers of the last step, [N][...]: 0 encoding [pitch], 1 layer-1
+ * pre-activation (after the backward pass: its error), 2 layer-1 activation, 3 first MLP's output
+ * (after backward: its gradient), 4 layer-3 pre-activation, 5 layer-3 activation (after backward: error) */
+const unsigned short* nerf_trainer_buffer_bf16(NerfTrainer* tr, int which);
 
 /* ---- forward-only render (nerf.c:259-316 for a whole view, chunked over rays) ------------------ */
 /* host_rgb8 [render_h*render_w*3] and/or host_pixel [render_h*render_w*3] (either may be NULL) */

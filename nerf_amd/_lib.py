@@ -66,7 +66,7 @@ class NerfTrainerConfig(C.Structure):  # include/nerf_amd.h
         ("near_plane", C.c_float), ("far_plane", C.c_float),
         ("pos_enc_l", C.c_int), ("dir_enc_l", C.c_int),
         ("hidden_dim", C.c_int), ("intermediate_dim", C.c_int), ("output_dim", C.c_int),
-        ("learning_rate", C.c_float),
+        ("learning_rate", C.c_float), ("precision", C.c_int),
     ]
 
 
@@ -113,6 +113,8 @@ _SIGS = {
     "nerf_draw_ray_indices": (None, [C.POINTER(Dataset), C.c_int, c_int_p]),
     "nerf_encode_batch": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, VP,
                                     C.c_int, VP, VP]),
+    "nerf_encode_batch_bf16": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, VP,
+                                         C.c_int, VP]),
     "nerf_encode_vector": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "nerf_encode_points": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, C.c_int]),
     "nerf_encode_view": (C.c_int, [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
@@ -165,7 +167,9 @@ _SIGS = {
     "nerf_trainer_get_params": (C.c_int, [VP, VP]),
     "nerf_trainer_adopt": (C.c_int, [VP, C.POINTER(MLP), C.POINTER(MLP)]),
     "nerf_trainer_forward_backward": (C.c_int, [VP, VP, VP, VP]),
+    "nerf_trainer_forward_backward_add": (C.c_int, [VP, VP, VP, VP]),
     "nerf_trainer_forward_backward_points": (C.c_int, [VP, VP, VP]),
+    "nerf_trainer_buffer_bf16": (VP, [VP, C.c_int]),
     "nerf_trainer_update": (C.c_int, [VP, C.c_float, C.c_int]),
     "nerf_trainer_step": (C.c_int, [VP, VP, VP, VP]),
     "nerf_trainer_last_loss": (C.c_float, [VP]),

@@ -237,6 +237,22 @@ class Trainer:
         _check(lib.nerf_trainer_forward_backward(self.handle, dds.handle, d_idx.ptr, d_offsets.ptr if d_offsets else 0),
                "nerf_trainer_forward_backward")
 
+    def forward_backward_add(self, dds, d_idx, d_offsets=None):
+        """micro-batching: adds this batch's gradient sums and squared error to the arena"""
+        _check(lib.nerf_trainer_forward_backward_add(self.handle, dds.handle, d_idx.ptr,
+                                                     d_offsets.ptr if d_offsets else 0),
+               "nerf_trainer_forward_backward_add")
+
+    def buffer_bf16(self, which):
+        """bf16 precision: 16-bit patterns of buffer `which` (see nerf_trainer_buffer_bf16), as uint16"""
+        c = self.cfg
+        ld = int(lib.nerf_trainer_encoding_pitch(self.handle))
+        widths = {0: ld, 1: c.hidden_dim, 2: c.hidden_dim, 3: c.intermediate_dim, 4: c.hidden_dim, 5: c.hidden_dim}
+        ptr = lib.nerf_trainer_buffer_bf16(self.handle, which)
+        if not ptr:
+            raise RuntimeError("not a bf16 trainer")
+        return device_to_numpy(ptr, (self.N, widths[which]), np.uint16)
+
     def forward_backward_points(self, d_batch_X, d_target):
         _check(lib.nerf_trainer_forward_backward_points(self.handle, d_batch_X.ptr, d_target.ptr),
                "nerf_trainer_forward_backward_points")

@@ -62,6 +62,7 @@ struct EncodeArgs {
     float near_plane, far_plane;
     int pos_l, dir_l;
     float* pe;                          // [N][ld_pe]
+    int pe_bf16;                        // pe points at 16-bit bf16 values (rounded to nearest even) instead of floats
     int ld_pe;
     float* target;                      // [R][3] or null (SRC_INDICES only)
     float* batch_X_out;                 // [N][6] or null: also emit the raw samples
@@ -92,6 +93,18 @@ __device__ __forceinline__ float sample_depth(int s, int S, float near_plane, fl
     return __fadd_rn(near_plane, __fdiv_rn(__fmul_rn(__fsub_rn(far_plane, near_plane), fs), (float)(S - 1)));
 }
 
+// one encoded value: fp32 as is, or rounded to bf16 when the buffer is 16-bit
+template <bool BF16>
+__device__ __forceinline__ void put(float* base, size_t index, float v) {
+    if (BF16) {
+        const __bf16 b = (__bf16)v;
+        reinterpret_cast<unsigned short*>(base)[index] = __builtin_bit_cast(unsigned short, b);
+    } else {
+        base[index] = v;
+    }
+}
+
+template <bool BF16>
 __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a) {
     const int pos_w = NERF_PE_DIM3(a.pos_l);
     // without an encoding buffer only the raw samples are wanted: one work item per point
@@ -140,11 +153,12 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a) {
         x[3] = dir[0]; x[4] = dir[1]; x[5] = dir[2];
     }
     if (!a.pe) return;
-    float* row = a.pe + point * a.ld_pe;
+    const size_t row = (size_t)point * a.ld_pe;
     if (slot == 0) {
-        row[0] = pos[0]; row[1] = pos[1]; row[2] = pos[2];
+        put<BF16>(a.pe, row + 0, pos[0]); put<BF16>(a.pe, row + 1, pos[1]); put<BF16>(a.pe, row + 2, pos[2]);
     } else if (slot == slots_pos) {
-        row[pos_w + 0] = dir[0]; row[pos_w + 1] = dir[1]; row[pos_w + 2] = dir[2];
+        put<BF16>(a.pe, row + pos_w + 0, dir[0]); put<BF16>(a.pe, row + pos_w + 1, dir[1]);
+        put<BF16>(a.pe, row + pos_w + 2, dir[2]);
     } else {
         const bool is_dir = slot > slots_pos;
         const int k = is_dir ? slot - slots_pos - 1 : slot - 1;
@@ -155,9 +169,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a) {
         const float arg = (float)(__dmul_rn(__dmul_rn(freq, 3.14159265358979323846), (double)x));
         float sv, cv;
         sincosf(arg, &sv, &cv);
-        float* dst = row + (is_dir ? pos_w : 0) + 3 + 6 * l + 2 * i;
-        dst[0] = sv;
-        dst[1] = cv;
+        const size_t dst = row + (is_dir ? pos_w : 0) + 3 + 6 * l + 2 * i;
+        put<BF16>(a.pe, dst, sv);
+        put<BF16>(a.pe, dst + 1, cv);
     }
 }
 
@@ -185,7 +199,10 @@ int launch_encode(const EncodeArgs& a) {
     const long long total = (long long)a.R * a.S * slots;
     const long long grid = (total + 255) / 256;
     if (grid > 0x7fffffffLL) return NERF_ERR_ARG;
-    hipLaunchKernelGGL(encode_kernel, dim3((unsigned)grid), dim3(256), 0, stream(), a);
+    if (a.pe_bf16)
+        hipLaunchKernelGGL(encode_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
+    else
+        hipLaunchKernelGGL(encode_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
@@ -262,6 +279,21 @@ int nerf_encode_batch(const NerfDeviceDataset* dds, const int* d_idx, const floa
     a.offsets = d_offsets; a.R = R; a.S = S; a.near_plane = near_plane; a.far_plane = far_plane;
     a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = d_pe; a.ld_pe = ld_pe; a.target = d_target;
     a.batch_X_out = d_batch_X;
+    return launch_encode(a);
+}
+
+// nerf_encode_batch with the encoding rounded to bf16 (the reduced-precision trainer's input)
+int nerf_encode_batch_bf16(const NerfDeviceDataset* dds, const int* d_idx, const float* d_offsets, int R, int S,
+                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, unsigned short* d_pe,
+                           int ld_pe, float* d_target) {
+    if (!dds || !d_idx || !d_pe) return NERF_ERR_ARG;
+    if (d_target && !dds->d_pixels) return NERF_ERR_ARG;
+    EncodeArgs a = {};
+    a.source = SRC_INDICES;
+    a.cams = dds->d_cams; a.pixels = dds->d_pixels; a.img_off = dds->d_img_off; a.idx = d_idx;
+    a.offsets = d_offsets; a.R = R; a.S = S; a.near_plane = near_plane; a.far_plane = far_plane;
+    a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = reinterpret_cast<float*>(d_pe); a.pe_bf16 = 1; a.ld_pe = ld_pe;
+    a.target = d_target;
     return launch_encode(a);
 }
 

@@ -331,7 +331,8 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
 // Builds an MLP whose parameter-sized buffers live where the caller says (a trainer's flat arenas)
 // or, with params == nullptr, in allocations of its own.
 MLP* mlp_create(int input_dim, int hidden_dim, int output_dim, int batch_size, void* handle, float* W1, float* W2,
-                float* g1, float* g2, float* m1, float* v1, float* m2, float* v2, bool forward_only) {
+                float* g1, float* g2, float* m1, float* v1, float* m2, float* v2, int buffers) {
+    const bool forward_only = buffers == MLP_FORWARD_ONLY, params_only = buffers == MLP_PARAMS_ONLY;
     if (input_dim <= 0 || hidden_dim <= 0 || output_dim <= 0 || batch_size <= 0) return nullptr;
     MLP* mlp = (MLP*)calloc(1, sizeof(MLP));
     if (!mlp) return nullptr;
@@ -356,8 +357,8 @@ MLP* mlp_create(int input_dim, int hidden_dim, int output_dim, int batch_size, v
         dalloc(&mlp->d_W1_m, n1); dalloc(&mlp->d_W1_v, n1);
         dalloc(&mlp->d_W2_m, n2); dalloc(&mlp->d_W2_v, n2);
     }
-    dalloc(&mlp->d_layer_postact, bh); dalloc(&mlp->d_layer_output, bo);
-    if (!forward_only) {
+    if (!params_only) { dalloc(&mlp->d_layer_postact, bh); dalloc(&mlp->d_layer_output, bo); }
+    if (!forward_only && !params_only) {
         dalloc(&mlp->d_layer_preact, bh);  // only the backward pass reads the pre-activation
         dalloc(&mlp->d_error_hidden, bh); dalloc(&mlp->d_error_output, bo);
         mlp->workspace_bytes = mlp_workspace_bytes(input_dim, hidden_dim, output_dim, batch_size);
@@ -414,7 +415,17 @@ void free_mlp(MLP* mlp) {
     free(mlp);
 }
 
+// An MLP that only carries parameters (the bf16 trainer's view of its weights) has no activation buffers.
+static void require_activations(const MLP* mlp, const char* what, bool backward) {
+    if (!mlp->d_layer_postact || (backward && !mlp->d_error_hidden)) {
+        fprintf(stderr, "%s: this MLP has no %s buffers (a parameter-only or forward-only view)\n", what,
+                backward ? "backward" : "activation");
+        exit(EXIT_FAILURE);
+    }
+}
+
 void forward_pass_mlp(MLP* mlp, float* d_X) {
+    require_activations(mlp, "forward_pass_mlp", false);
     mlp_forward(mlp, d_X);
     NERF_HIP_CHECK(hipGetLastError());
 }
@@ -425,6 +436,7 @@ void zero_gradients_mlp(MLP* mlp) {
 }
 
 void backward_pass_mlp(MLP* mlp, float* d_X, float* d_grad_X) {
+    require_activations(mlp, "backward_pass_mlp", true);
     mlp_backward(mlp, d_X, mlp->input_dim, d_grad_X, 1);
     NERF_HIP_CHECK(hipGetLastError());
 }

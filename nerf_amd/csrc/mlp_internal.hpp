@@ -6,10 +6,12 @@
 namespace nerf {
 
 // An MLP whose weight/gradient/moment buffers are the given device pointers (W1 != nullptr: the
-// caller keeps ownership) or fresh allocations (W1 == nullptr).  forward_only skips the error
-// buffers and the weight-gradient workspace.
+// caller keeps ownership) or fresh allocations (W1 == nullptr).  `buffers`: MLP_FORWARD_ONLY skips
+// the error buffers, the pre-activation and the weight-gradient workspace; MLP_PARAMS_ONLY
+// allocates no per-point buffer at all (a view of the weights for checkpoints).
+enum { MLP_FULL = 0, MLP_FORWARD_ONLY = 1, MLP_PARAMS_ONLY = 2 };
 MLP* mlp_create(int input_dim, int hidden_dim, int output_dim, int batch_size, void* handle, float* W1, float* W2,
-                float* g1, float* g2, float* m1, float* v1, float* m2, float* v2, bool forward_only);
+                float* g1, float* g2, float* m1, float* v1, float* m2, float* v2, int buffers);
 // The input of layer 1 as the fast matrix path wants it: rows of `ld` floats (ld >= input_dim, the
 // tail of every row zero) and, if ld != input_dim, a copy of W1 with the same pitch and zero tail.
 // The products then run over `ld` contraction steps; the zero tails add exact zeros.

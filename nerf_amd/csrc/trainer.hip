@@ -16,6 +16,7 @@
 // layout [mlp1.W1 | mlp1.W2 | mlp2.W1 | mlp2.W2]; the gradient arena has one extra slot for the
 // summed squared error so that a data-parallel caller all-reduces a single buffer.
 #include "mlp_internal.hpp"
+#include "trainer_bf16.hpp"
 #include "../../include/nerf_amd.h"
 #include "../../include/nerf_kernels.h"
 #include "../../include/nerf_spec.h"
@@ -45,6 +46,7 @@ struct NerfTrainer {
     float* d_err;     // [R][3]
     float learning_rate;
     int steps;
+    Bf16Step* bf;     // non-null in the bf16-operand configuration (then d_pe, d_w1p and the MLPs' activations are absent)
 };
 
 namespace {
@@ -91,12 +93,46 @@ PitchedInput encoded_input(NerfTrainer* tr) {
     return in;
 }
 
-int after_forward(NerfTrainer* tr) {
+// Compositing, loss and the compositing gradient on the MLP's raw output (train.c:192-212).
+int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int accumulate) {
+    const int R = tr->cfg.rays_per_batch, S = tr->cfg.num_samples;
+    float* loss = tr->d_grads + tr->n_params;
+    if (!accumulate && hipMemsetAsync(loss, 0, 4 * sizeof(float), stream()) != hipSuccess) return NERF_ERR_HIP;
+    int rc;
+    {
+        ProfScope prof(K_COMPOSITE_FWD, (double)R * S * 16.0 + (double)R * 36.0);
+        rc = nerf_composite_forward(raw, tr->cfg.output_dim, tr->d_target, 3, nullptr, nullptr, tr->d_pixel, tr->d_err,
+                                    R, S);
+    }
+    if (rc != NERF_OK) return rc;
+    {
+        ProfScope prof(K_LOSS, (double)R * 12.0);
+        rc = nerf_loss_accumulate(tr->d_err, R, loss);
+    }
+    if (rc != NERF_OK) return rc;
+    ProfScope prof(K_COMPOSITE_BWD, (double)R * S * 32.0 + (double)R * 12.0);
+    return nerf_composite_backward(raw, tr->cfg.output_dim, tr->d_err, draw, R, S);
+}
+
+int after_forward_bf16(NerfTrainer* tr, int accumulate) {
+    Bf16Step* bf = tr->bf;
+    float *P = tr->d_params, *G = tr->d_grads;
+    const size_t* o = tr->off;
+    int rc = bf16_step_refresh_weights(bf, P + o[0], P + o[1], P + o[2]);
+    if (rc == NERF_OK) rc = bf16_step_forward(bf, P + o[3]);
+    if (rc == NERF_OK) rc = composite_and_gradient(tr, bf->raw, bf->draw, accumulate);
+    if (rc == NERF_OK) rc = bf16_step_backward(bf, P + o[3], G + o[0], G + o[1], G + o[2], G + o[3], accumulate);
+    if (rc != NERF_OK) return rc;
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+int after_forward(NerfTrainer* tr, int accumulate) {
+    if (tr->bf) return after_forward_bf16(tr, accumulate);
     const int R = tr->cfg.rays_per_batch, S = tr->cfg.num_samples;
     float* loss = tr->d_grads + tr->n_params;
     mlp_forward(tr->mlp1, encoded_input(tr));
     mlp_forward(tr->mlp2, tr->mlp1->d_layer_output);
-    if (hipMemsetAsync(loss, 0, 4 * sizeof(float), stream()) != hipSuccess) return NERF_ERR_HIP;
+    if (!accumulate && hipMemsetAsync(loss, 0, 4 * sizeof(float), stream()) != hipSuccess) return NERF_ERR_HIP;
     int rc;
     {
         ProfScope prof(K_COMPOSITE_FWD, (double)R * S * 16.0 + (double)R * 36.0);
@@ -115,8 +151,8 @@ int after_forward(NerfTrainer* tr) {
                                      tr->mlp2->d_error_output, R, S);
     }
     if (rc != NERF_OK) return rc;
-    mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp2->input_dim, tr->mlp1->d_error_output, 0);
-    mlp_backward(tr->mlp1, tr->d_pe, tr->pe_ld, nullptr, 0);
+    mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp2->input_dim, tr->mlp1->d_error_output, accumulate);
+    mlp_backward(tr->mlp1, tr->d_pe, tr->pe_ld, nullptr, accumulate);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
@@ -135,6 +171,7 @@ void nerf_trainer_default_config(NerfTrainerConfig* cfg) {
     cfg->intermediate_dim = NERF_DEFAULT_INTERMEDIATE_DIM;
     cfg->output_dim = NERF_DEFAULT_OUTPUT_DIM;
     cfg->learning_rate = NERF_DEFAULT_LR;
+    cfg->precision = NERF_PRECISION_F32;
 }
 
 size_t nerf_trainer_param_count(const NerfTrainerConfig* c) {
@@ -148,6 +185,11 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
         cfg->output_dim != 4 || cfg->hidden_dim <= 0 || cfg->intermediate_dim <= 0)
         return nullptr;
     if ((long long)cfg->rays_per_batch * cfg->num_samples > 0x7fffffffLL) return nullptr;
+    if (cfg->precision != NERF_PRECISION_F32 && cfg->precision != NERF_PRECISION_BF16) return nullptr;
+    const bool bf16 = cfg->precision == NERF_PRECISION_BF16;
+    if (bf16 && !bf16_step_supported(NERF_PE_DIM3(cfg->pos_enc_l) + NERF_PE_DIM3(cfg->dir_enc_l), cfg->hidden_dim,
+                                     cfg->intermediate_dim, cfg->output_dim))
+        return nullptr;
     NerfTrainer* tr = (NerfTrainer*)calloc(1, sizeof(NerfTrainer));
     if (!tr) return nullptr;
     tr->cfg = *cfg;
@@ -168,23 +210,30 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
     dalloc(&tr->d_m, tr->n_params);
     dalloc(&tr->d_v, tr->n_params);
     tr->pe_ld = ((tr->pe_dim + 31) / 32) * 32;
-    dalloc(&tr->d_pe, (size_t)N * tr->pe_ld);
-    if (tr->pe_ld != tr->pe_dim) dalloc(&tr->d_w1p, (size_t)H * tr->pe_ld);
+    if (!bf16) {
+        dalloc(&tr->d_pe, (size_t)N * tr->pe_ld);
+        if (tr->pe_ld != tr->pe_dim) dalloc(&tr->d_w1p, (size_t)H * tr->pe_ld);
+    }
     dalloc(&tr->d_target, (size_t)R * 3);
     dalloc(&tr->d_pixel, (size_t)R * 3);
     dalloc(&tr->d_err, (size_t)R * 3);
     if (ok) {
         float *P = tr->d_params, *G = tr->d_grads, *Mo = tr->d_m, *V = tr->d_v;
         const size_t* o = tr->off;
+        const int buffers = bf16 ? MLP_PARAMS_ONLY : MLP_FULL;
         tr->mlp1 = mlp_create(tr->pe_dim, H, M, N, nullptr, P + o[0], P + o[1], G + o[0], G + o[1], Mo + o[0], V + o[0],
-                              Mo + o[1], V + o[1], false);
+                              Mo + o[1], V + o[1], buffers);
         tr->mlp2 = mlp_create(M, H, O, N, nullptr, P + o[2], P + o[3], G + o[2], G + o[3], Mo + o[2], V + o[2],
-                              Mo + o[3], V + o[3], false);
+                              Mo + o[3], V + o[3], buffers);
         ok = tr->mlp1 && tr->mlp2;
+        if (ok && bf16) {
+            tr->bf = bf16_step_create(tr->pe_dim, H, M, O, N);
+            ok = tr->bf != nullptr;
+        }
     }
     if (!ok) { nerf_trainer_destroy(tr); return nullptr; }
     // the row tails stay zero for the trainer's lifetime: the encoder writes pe_dim floats per row
-    NERF_HIP_CHECK(hipMemsetAsync(tr->d_pe, 0, (size_t)N * tr->pe_ld * 4, stream()));
+    if (tr->d_pe) NERF_HIP_CHECK(hipMemsetAsync(tr->d_pe, 0, (size_t)N * tr->pe_ld * 4, stream()));
     if (tr->d_w1p) NERF_HIP_CHECK(hipMemsetAsync(tr->d_w1p, 0, (size_t)H * tr->pe_ld * 4, stream()));
     NERF_HIP_CHECK(hipMemsetAsync(tr->d_m, 0, tr->n_params * 4, stream()));
     NERF_HIP_CHECK(hipMemsetAsync(tr->d_v, 0, tr->n_params * 4, stream()));
@@ -198,6 +247,7 @@ void nerf_trainer_destroy(NerfTrainer* tr) {
     if (!tr) return;
     if (tr->mlp1) free_mlp(tr->mlp1);
     if (tr->mlp2) free_mlp(tr->mlp2);
+    bf16_step_destroy(tr->bf);
     if (tr->owns_params) hipFree(tr->d_params);
     if (tr->owns_grads) hipFree(tr->d_grads);
     hipFree(tr->d_m); hipFree(tr->d_v); hipFree(tr->d_pe); hipFree(tr->d_w1p);
@@ -259,22 +309,37 @@ int nerf_trainer_adopt(NerfTrainer* tr, const MLP* mlp1, const MLP* mlp2) {
     return hipStreamSynchronize(stream()) == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
-int nerf_trainer_forward_backward(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
-                                  const float* d_offsets) {
+static int forward_backward_impl(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
+                                 const float* d_offsets, int accumulate) {
     if (!tr || !dataset || !d_idx) return NERF_ERR_ARG;
     const NerfTrainerConfig& c = tr->cfg;
     int rc;
     {
-        ProfScope prof(K_ENCODE, (double)c.rays_per_batch * c.num_samples * tr->pe_dim * 4.0);
-        rc = nerf_encode_batch(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane, c.far_plane,
-                               c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld, tr->d_target, nullptr);
+        ProfScope prof(K_ENCODE, (double)c.rays_per_batch * c.num_samples * tr->pe_dim * (tr->bf ? 2.0 : 4.0));
+        if (tr->bf)
+            rc = nerf_encode_batch_bf16(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane,
+                                        c.far_plane, c.pos_enc_l, c.dir_enc_l, tr->bf->enc, tr->bf->pe_ld, tr->d_target);
+        else
+            rc = nerf_encode_batch(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane, c.far_plane,
+                                   c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld, tr->d_target, nullptr);
     }
     if (rc != NERF_OK) return rc;
-    return after_forward(tr);
+    return after_forward(tr, accumulate);
+}
+
+int nerf_trainer_forward_backward(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
+                                  const float* d_offsets) {
+    return forward_backward_impl(tr, dataset, d_idx, d_offsets, 0);
+}
+
+int nerf_trainer_forward_backward_add(NerfTrainer* tr, const NerfDeviceDataset* dataset, const int* d_idx,
+                                      const float* d_offsets) {
+    return forward_backward_impl(tr, dataset, d_idx, d_offsets, 1);
 }
 
 int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X, const float* d_target) {
     if (!tr || !d_batch_X || !d_target) return NERF_ERR_ARG;
+    if (tr->bf) return NERF_ERR_ARG;  // host-supplied samples are an fp32-path facility
     const NerfTrainerConfig& c = tr->cfg;
     const int N = c.rays_per_batch * c.num_samples;
     int rc;
@@ -286,7 +351,7 @@ int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X
     if (hipMemcpyAsync(tr->d_target, d_target, (size_t)c.rays_per_batch * 3 * sizeof(float), hipMemcpyDeviceToDevice,
                        stream()) != hipSuccess)
         return NERF_ERR_HIP;
-    return after_forward(tr);
+    return after_forward(tr, 0);
 }
 
 int nerf_trainer_update(NerfTrainer* tr, float learning_rate, int grad_points) {
@@ -319,9 +384,32 @@ float nerf_trainer_last_loss(NerfTrainer* tr) {
 float nerf_trainer_learning_rate(const NerfTrainer* tr) { return tr->learning_rate; }
 int nerf_trainer_steps_done(const NerfTrainer* tr) { return tr->mlp1->t; }
 
-int nerf_trainer_encoding_pitch(const NerfTrainer* tr) { return tr->pe_ld; }
+int nerf_trainer_encoding_pitch(const NerfTrainer* tr) { return tr->bf ? tr->bf->pe_ld : tr->pe_ld; }
+
+const unsigned short* nerf_trainer_buffer_bf16(NerfTrainer* tr, int which) {
+    if (!tr || !tr->bf) return nullptr;
+    switch (which) {
+        case 0: return tr->bf->enc;
+        case 1: return tr->bf->pre1;
+        case 2: return tr->bf->act1;
+        case 3: return tr->bf->y1;
+        case 4: return tr->bf->pre2;
+        case 5: return tr->bf->act2;
+        default: return nullptr;
+    }
+}
 
 const float* nerf_trainer_buffer(NerfTrainer* tr, int which) {
+    if (tr->bf) {
+        switch (which) {
+            case 1: return tr->bf->raw;
+            case 2: return tr->d_pixel;
+            case 3: return tr->d_err;
+            case 4: return tr->d_target;
+            case 5: return tr->bf->draw;
+            default: return nullptr;
+        }
+    }
     switch (which) {
         case 0: return tr->d_pe;
         case 1: return tr->mlp2->d_layer_output;
