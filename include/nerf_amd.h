@@ -127,6 +127,21 @@ int nerf_loss_accumulate(const float* d_err, int R, float* d_loss);
 /* activation + volume_rendering_gradient_kernel (nerf.c:63-127) from the raw output (out_dim 4) */
 int nerf_composite_backward(const float* d_raw, int out_dim, const float* d_err, float* d_error_output, int R, int S);
 
+/* ---- opt-in quadrature with the true sample spacing: NOT the reference's arithmetic (which uses the
+ * constant 0.01 and stops at transmittance 0.01).  delta_s = t_{s+1} - t_s with the depths
+ * nerf_encode_batch gives the samples (d_offsets as there, may be NULL), delta_{S-1} = 1e10,
+ * alpha_s = 1 - exp(-density_s delta_s), no early stop; the backward form is the analytic gradient
+ * of 1/2 sum err^2. ------------------------------------------------------------------------------ */
+int nerf_composite_forward_spacing(const float* d_raw, int out_dim, const float* d_offsets, float near_plane,
+                                   float far_plane, const float* d_target, int target_stride, float* d_pixel,
+                                   float* d_err, int R, int S);
+int nerf_composite_backward_spacing(const float* d_raw, int out_dim, const float* d_offsets, float near_plane,
+                                    float far_plane, const float* d_err, float* d_error_output, int R, int S);
+/* d_offsets[i] = uniform [0,1) for i < count, a pure function of (seed, batch, i): stratified
+ * sampling (one jittered sample per spacing interval) when passed as d_offsets.  The reference
+ * samples without jitter (nerf.c:187). */
+int nerf_stratified_offsets(float* d_offsets, long count, unsigned long long seed, unsigned long long batch);
+
 /* ---- trainer: the loop body of train.c:169-220 with every stage on the device ------------------ */
 typedef struct NerfTrainer NerfTrainer;
 typedef struct {
@@ -136,7 +151,9 @@ typedef struct {
     int hidden_dim, intermediate_dim, output_dim; /* train.c:42-44 */
     float learning_rate;                        /* train.c:160 */
     int precision;                              /* NERF_PRECISION_F32 (the reference's arithmetic) or _BF16 */
+    int quadrature;                             /* NERF_QUADRATURE_REFERENCE or _SPACING (see nerf_composite_*_spacing) */
 } NerfTrainerConfig;
+enum { NERF_QUADRATURE_REFERENCE = 0, NERF_QUADRATURE_SPACING = 1 };
 /* NERF_PRECISION_BF16: activations and the weights as the matrix cores read them are bf16, products
  * accumulate in fp32, master weights / gradients / AdamW / compositing stay fp32.  Needs hidden and
  * intermediate widths that are multiples of 64.  No counterpart in the reference. */

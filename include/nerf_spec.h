@@ -19,6 +19,9 @@
 /* forward compositing stops after the sample that takes transmittance below this value.
  * reference nerf.c:43, nerf.c:308.  The gradient kernel has no such stop (nerf.c:77-87). */
 #define NERF_T_STOP 0.01f
+/* Opt-in quadrature with the true spacing delta_s = t_{s+1} - t_s (not the reference's): spacing
+ * assigned to the last sample, as in the original NeRF formulation. */
+#define NERF_LAST_DELTA 1e10f
 
 /* ---- default training configuration (PINNED, reference train.c:16-25,42-44,159-173) --- */
 #define NERF_DEFAULT_RAYS_PER_BATCH 16

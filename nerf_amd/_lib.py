@@ -66,7 +66,7 @@ class NerfTrainerConfig(C.Structure):  # include/nerf_amd.h
         ("near_plane", C.c_float), ("far_plane", C.c_float),
         ("pos_enc_l", C.c_int), ("dir_enc_l", C.c_int),
         ("hidden_dim", C.c_int), ("intermediate_dim", C.c_int), ("output_dim", C.c_int),
-        ("learning_rate", C.c_float), ("precision", C.c_int),
+        ("learning_rate", C.c_float), ("precision", C.c_int), ("quadrature", C.c_int),
     ]
 
 
@@ -122,6 +122,10 @@ _SIGS = {
     # compositing
     "nerf_composite_forward": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP, VP, VP, C.c_int, C.c_int]),
     "nerf_loss_accumulate": (C.c_int, [VP, C.c_int, VP]),
+    "nerf_composite_forward_spacing": (C.c_int, [VP, C.c_int, VP, C.c_float, C.c_float, VP, C.c_int, VP, VP, C.c_int,
+                                                 C.c_int]),
+    "nerf_composite_backward_spacing": (C.c_int, [VP, C.c_int, VP, C.c_float, C.c_float, VP, VP, C.c_int, C.c_int]),
+    "nerf_stratified_offsets": (C.c_int, [VP, C.c_long, C.c_ulonglong, C.c_ulonglong]),
     "nerf_composite_backward": (C.c_int, [VP, C.c_int, VP, VP, C.c_int, C.c_int]),
     "activation_kernel_launch": (None, [VP, VP, VP, C.c_int, C.c_int]),
     "volume_rendering_and_loss_launch": (None, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int]),

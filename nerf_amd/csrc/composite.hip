@@ -18,6 +18,12 @@
 //             composition of the affine maps x -> (1-a_s) x + (1-a_s) a_{s+1} q_{s+1}.
 //             No early stop here (nerf.c:77-87 has none).
 // Both kernels are HBM-bound: 16 B read (+16 B written) per sample.
+//
+// SPACING = true is an opt-in quadrature that is NOT the reference's: alpha_s = 1 - exp(-dens_s delta_s)
+// with the true spacing delta_s = t_{s+1} - t_s of the (possibly jittered) sample depths,
+// delta_{S-1} = NERF_LAST_DELTA, no early stop, and the analytic gradient
+//   dL/ddens_s = delta_s ((1 - alpha_s) T_s q_s - sum_{t>s} w_t q_t)
+// whose suffix sum is a reverse additive scan across the wavefront.
 #include "common.hpp"
 #include "../../include/nerf_spec.h"
 
@@ -52,6 +58,29 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
+// exclusive suffix sum over the 64 lanes: lane l receives sum of x over lanes > l
+__device__ __forceinline__ float wave_exclusive_suffix_sum(float x, int lane) {
+    float incl = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float y = __shfl_down(incl, d, 64);
+        if (lane + d < 64) incl += y;
+    }
+    const float ex = __shfl_down(incl, 1, 64);
+    return lane == 63 ? 0.0f : ex;
+}
+
+// depth of sample s exactly as the encoder places it (nerf.c:187 with an optional offset in units of
+// one spacing), and the spacing the opt-in quadrature gives that sample
+__device__ __forceinline__ float sample_depth_of(int s, int S, float near_plane, float far_plane, const float* off) {
+    const float fs = off ? __fadd_rn((float)s, off[s]) : (float)s;
+    return __fadd_rn(near_plane, __fdiv_rn(__fmul_rn(__fsub_rn(far_plane, near_plane), fs), (float)(S - 1)));
+}
+__device__ __forceinline__ float sample_spacing(int s, int S, float near_plane, float far_plane, const float* off) {
+    if (s == S - 1) return NERF_LAST_DELTA;
+    return __fsub_rn(sample_depth_of(s + 1, S, near_plane, far_plane, off), sample_depth_of(s, S, near_plane, far_plane, off));
+}
+
 // Loads one sample's density and colour.  RAW: from the MLP's raw output row (activation applied
 // here: ReLU on channel 0, sigmoid on 1..3, nerf.c:13-17).  Otherwise from dens[] / rgb[].
 template <bool RAW>
@@ -73,11 +102,16 @@ __device__ __forceinline__ void load_sample(const float* __restrict__ raw, int o
     }
 }
 
-template <int SPL, bool RAW>
+struct SpacingArgs {
+    const float* offsets;  // [R][S] or null
+    float near_plane, far_plane;
+};
+
+template <int SPL, bool RAW, bool SPACING>
 __global__ __launch_bounds__(256) void composite_forward_kernel(
     const float* __restrict__ raw, int out_dim, const float* __restrict__ dens_in, const float* __restrict__ rgb_in,
     const float* __restrict__ target, int target_stride, float* __restrict__ dens_out, float* __restrict__ rgb_out,
-    float* __restrict__ pixel, float* __restrict__ err, int R, int S) {
+    float* __restrict__ pixel, float* __restrict__ err, int R, int S, SpacingArgs sp) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= R) return;  // whole wavefront leaves together
@@ -97,7 +131,12 @@ __global__ __launch_bounds__(256) void composite_forward_kernel(
                 dens_out[p] = d;
                 rgb_out[p * 3 + 0] = col[i][0]; rgb_out[p * 3 + 1] = col[i][1]; rgb_out[p * 3 + 2] = col[i][2];
             }
-            alpha[i] = 1.0f - expf_cr(-d * NERF_DELTA);  // nerf.c:35
+            if (SPACING) {
+                const float* off = sp.offsets ? sp.offsets + (size_t)ray * S : nullptr;
+                alpha[i] = 1.0f - expf_cr(-d * sample_spacing(s, S, sp.near_plane, sp.far_plane, off));
+            } else {
+                alpha[i] = 1.0f - expf_cr(-d * NERF_DELTA);  // nerf.c:35
+            }
         }
         local *= (1.0f - alpha[i]);
     }
@@ -105,7 +144,7 @@ __global__ __launch_bounds__(256) void composite_forward_kernel(
     float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
-        if (T >= NERF_T_STOP) {  // equivalent to nerf.c:42-43 because T is non-increasing
+        if (SPACING || T >= NERF_T_STOP) {  // equivalent to nerf.c:42-43 because T is non-increasing
             const float w = alpha[i] * T;
             acc[0] += w * col[i][0]; acc[1] += w * col[i][1]; acc[2] += w * col[i][2];
         }
@@ -134,26 +173,30 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
     if (threadIdx.x == 0) loss[0] += part[0];
 }
 
-template <int SPL, bool RAW>
+template <int SPL, bool RAW, bool SPACING>
 __global__ __launch_bounds__(256) void composite_backward_kernel(
     const float* __restrict__ raw, int out_dim, const float* __restrict__ dens_in, const float* __restrict__ rgb_in,
-    const float* __restrict__ err, float* __restrict__ d_out, int R, int S) {
+    const float* __restrict__ err, float* __restrict__ d_out, int R, int S, SpacingArgs sp) {
     const int lane = threadIdx.x & 63;
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= R) return;
     const float e0 = err[ray * 3 + 0], e1 = err[ray * 3 + 1], e2 = err[ray * 3 + 2];
 
-    float alpha[SPL], col[SPL][3], dens[SPL], q[SPL];
+    float alpha[SPL], col[SPL][3], dens[SPL], q[SPL], delta[SPL];
     float local = 1.0f;
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
         const int s = lane * SPL + i;
-        alpha[i] = 0.0f; dens[i] = 0.0f; q[i] = 0.0f;
+        alpha[i] = 0.0f; dens[i] = 0.0f; q[i] = 0.0f; delta[i] = NERF_DELTA;
         col[i][0] = col[i][1] = col[i][2] = 0.0f;
         if (s < S) {
             const size_t p = (size_t)ray * S + s;
             load_sample<RAW>(raw, out_dim, dens_in, rgb_in, p, dens[i], col[i]);
-            alpha[i] = 1.0f - expf_cr(-dens[i] * NERF_DELTA);                  // nerf.c:79
+            if (SPACING) {
+                const float* off = sp.offsets ? sp.offsets + (size_t)ray * S : nullptr;
+                delta[i] = sample_spacing(s, S, sp.near_plane, sp.far_plane, off);
+            }
+            alpha[i] = 1.0f - expf_cr(-dens[i] * delta[i]);                    // nerf.c:79
             q[i] = e0 * col[i][0] + e1 * col[i][1] + e2 * col[i][2];            // nerf.c:105-107
         }
         local *= (1.0f - alpha[i]);
@@ -167,6 +210,32 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
             Tbefore[i] = T;
             T *= (1.0f - alpha[i]);
         }
+    }
+    if (SPACING) {
+        // analytic gradient: tail_s = sum_{t>s} w_t q_t as a reverse additive scan
+        float wq[SPL], lane_sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < SPL; i++) {
+            wq[i] = alpha[i] * Tbefore[i] * q[i];
+            lane_sum += wq[i];
+        }
+        float tail = wave_exclusive_suffix_sum(lane_sum, lane);  // everything in the lanes after mine
+#pragma unroll
+        for (int i = SPL - 1; i >= 0; i--) {
+            const int s = lane * SPL + i;
+            if (s < S) {
+                const float w = alpha[i] * Tbefore[i];
+                const float gd = delta[i] * ((1.0f - alpha[i]) * Tbefore[i] * q[i] - tail);
+                f32x4 g;
+                g[0] = dens[i] > 0.0f ? gd : 0.0f;
+                g[1] = (w * e0) * (col[i][0] * (1.0f - col[i][0]));
+                g[2] = (w * e1) * (col[i][1] * (1.0f - col[i][1]));
+                g[3] = (w * e2) * (col[i][2] * (1.0f - col[i][2]));
+                *reinterpret_cast<f32x4*>(d_out + ((size_t)ray * S + s) * 4) = g;
+            }
+            tail += wq[i];
+        }
+        return;
     }
     // alpha*q of the sample that follows each of mine (0 past the end of the ray)
     float aq_next[SPL];
@@ -231,6 +300,19 @@ __global__ __launch_bounds__(256) void activation_kernel(const float* __restrict
     rgb[i * 3 + 2] = sigmoid_ref(o[3]);
 }
 
+// offsets[i] = uniform [0, 1) from a counter-based generator (splitmix64 of seed, batch and index):
+// one jittered sample per spacing interval, reproducible and independent of launch geometry
+__global__ __launch_bounds__(256) void stratified_offsets_kernel(float* __restrict__ out, long count,
+                                                                 unsigned long long seed, unsigned long long batch) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (batch * 0x100000001B3ULL + (unsigned long long)i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    out[i] = (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 int spl_for(int S) {
     const int need = (S + 63) / 64;
     for (int spl = 1; spl <= 16; spl <<= 1)
@@ -238,13 +320,14 @@ int spl_for(int S) {
     return 0;
 }
 
-template <bool RAW>
+template <bool RAW, bool SPACING = false>
 int launch_forward(const float* raw, int out_dim, const float* dens_in, const float* rgb_in, const float* target,
-                   int target_stride, float* dens_out, float* rgb_out, float* pixel, float* err, int R, int S) {
+                   int target_stride, float* dens_out, float* rgb_out, float* pixel, float* err, int R, int S,
+                   SpacingArgs sp = SpacingArgs{nullptr, 0.0f, 0.0f}) {
     const dim3 grid((R + 3) / 4), block(256);
 #define FWD(SPL)                                                                                                 \
-    hipLaunchKernelGGL((composite_forward_kernel<SPL, RAW>), grid, block, 0, stream(), raw, out_dim, dens_in,     \
-                       rgb_in, target, target_stride, dens_out, rgb_out, pixel, err, R, S)
+    hipLaunchKernelGGL((composite_forward_kernel<SPL, RAW, SPACING>), grid, block, 0, stream(), raw, out_dim,    \
+                       dens_in, rgb_in, target, target_stride, dens_out, rgb_out, pixel, err, R, S, sp)
     switch (spl_for(S)) {
         case 1: FWD(1); break;
         case 2: FWD(2); break;
@@ -257,13 +340,13 @@ int launch_forward(const float* raw, int out_dim, const float* dens_in, const fl
     return NERF_OK;
 }
 
-template <bool RAW>
+template <bool RAW, bool SPACING = false>
 int launch_backward(const float* raw, int out_dim, const float* dens_in, const float* rgb_in, const float* err,
-                    float* d_out, int R, int S) {
+                    float* d_out, int R, int S, SpacingArgs sp = SpacingArgs{nullptr, 0.0f, 0.0f}) {
     const dim3 grid((R + 3) / 4), block(256);
 #define BWD(SPL)                                                                                                 \
-    hipLaunchKernelGGL((composite_backward_kernel<SPL, RAW>), grid, block, 0, stream(), raw, out_dim, dens_in,    \
-                       rgb_in, err, d_out, R, S)
+    hipLaunchKernelGGL((composite_backward_kernel<SPL, RAW, SPACING>), grid, block, 0, stream(), raw, out_dim,   \
+                       dens_in, rgb_in, err, d_out, R, S, sp)
     switch (spl_for(S)) {
         case 1: BWD(1); break;
         case 2: BWD(2); break;
@@ -328,6 +411,35 @@ int nerf_composite_forward(const float* d_raw, int out_dim, const float* d_targe
     const int rc = launch_forward<true>(d_raw, out_dim, nullptr, nullptr, d_target, target_stride, d_dens, d_rgb,
                                         d_pixel, d_err, R, S);
     if (rc != NERF_OK) return rc;
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+// ---- opt-in quadrature with the true sample spacing (no counterpart in the reference) --------------
+
+int nerf_composite_forward_spacing(const float* d_raw, int out_dim, const float* d_offsets, float near_plane,
+                                   float far_plane, const float* d_target, int target_stride, float* d_pixel,
+                                   float* d_err, int R, int S) {
+    if (R <= 0 || S <= 1 || out_dim < 4 || !d_raw || !d_pixel) return NERF_ERR_ARG;
+    if (d_err && !d_target) return NERF_ERR_ARG;
+    const int rc = launch_forward<true, true>(d_raw, out_dim, nullptr, nullptr, d_target, target_stride, nullptr, nullptr,
+                                              d_pixel, d_err, R, S, SpacingArgs{d_offsets, near_plane, far_plane});
+    if (rc != NERF_OK) return rc;
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+int nerf_composite_backward_spacing(const float* d_raw, int out_dim, const float* d_offsets, float near_plane,
+                                    float far_plane, const float* d_err, float* d_error_output, int R, int S) {
+    if (R <= 0 || S <= 1 || out_dim != 4 || !d_raw || !d_err || !d_error_output) return NERF_ERR_ARG;
+    const int rc = launch_backward<true, true>(d_raw, out_dim, nullptr, nullptr, d_err, d_error_output, R, S,
+                                               SpacingArgs{d_offsets, near_plane, far_plane});
+    if (rc != NERF_OK) return rc;
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+int nerf_stratified_offsets(float* d_offsets, long count, unsigned long long seed, unsigned long long batch) {
+    if (!d_offsets || count <= 0) return NERF_ERR_ARG;
+    hipLaunchKernelGGL(stratified_offsets_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream(),
+                       d_offsets, count, seed, batch);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 

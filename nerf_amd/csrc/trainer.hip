@@ -46,6 +46,7 @@ struct NerfTrainer {
     float* d_err;     // [R][3]
     float learning_rate;
     int steps;
+    const float* d_offsets_last;  // the sample offsets of the step in flight (spacing quadrature reads them again)
     Bf16Step* bf;     // non-null in the bf16-operand configuration (then d_pe, d_w1p and the MLPs' activations are absent)
 };
 
@@ -95,14 +96,18 @@ PitchedInput encoded_input(NerfTrainer* tr) {
 
 // Compositing, loss and the compositing gradient on the MLP's raw output (train.c:192-212).
 int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int accumulate) {
-    const int R = tr->cfg.rays_per_batch, S = tr->cfg.num_samples;
+    const NerfTrainerConfig& c = tr->cfg;
+    const int R = c.rays_per_batch, S = c.num_samples;
+    const bool spacing = c.quadrature == NERF_QUADRATURE_SPACING;
     float* loss = tr->d_grads + tr->n_params;
     if (!accumulate && hipMemsetAsync(loss, 0, 4 * sizeof(float), stream()) != hipSuccess) return NERF_ERR_HIP;
     int rc;
     {
         ProfScope prof(K_COMPOSITE_FWD, (double)R * S * 16.0 + (double)R * 36.0);
-        rc = nerf_composite_forward(raw, tr->cfg.output_dim, tr->d_target, 3, nullptr, nullptr, tr->d_pixel, tr->d_err,
-                                    R, S);
+        rc = spacing ? nerf_composite_forward_spacing(raw, c.output_dim, tr->d_offsets_last, c.near_plane, c.far_plane,
+                                                      tr->d_target, 3, tr->d_pixel, tr->d_err, R, S)
+                     : nerf_composite_forward(raw, c.output_dim, tr->d_target, 3, nullptr, nullptr, tr->d_pixel,
+                                              tr->d_err, R, S);
     }
     if (rc != NERF_OK) return rc;
     {
@@ -111,7 +116,10 @@ int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int a
     }
     if (rc != NERF_OK) return rc;
     ProfScope prof(K_COMPOSITE_BWD, (double)R * S * 32.0 + (double)R * 12.0);
-    return nerf_composite_backward(raw, tr->cfg.output_dim, tr->d_err, draw, R, S);
+    if (spacing)
+        return nerf_composite_backward_spacing(raw, c.output_dim, tr->d_offsets_last, c.near_plane, c.far_plane, tr->d_err,
+                                               draw, R, S);
+    return nerf_composite_backward(raw, c.output_dim, tr->d_err, draw, R, S);
 }
 
 int after_forward_bf16(NerfTrainer* tr, int accumulate) {
@@ -128,28 +136,9 @@ int after_forward_bf16(NerfTrainer* tr, int accumulate) {
 
 int after_forward(NerfTrainer* tr, int accumulate) {
     if (tr->bf) return after_forward_bf16(tr, accumulate);
-    const int R = tr->cfg.rays_per_batch, S = tr->cfg.num_samples;
-    float* loss = tr->d_grads + tr->n_params;
     mlp_forward(tr->mlp1, encoded_input(tr));
     mlp_forward(tr->mlp2, tr->mlp1->d_layer_output);
-    if (!accumulate && hipMemsetAsync(loss, 0, 4 * sizeof(float), stream()) != hipSuccess) return NERF_ERR_HIP;
-    int rc;
-    {
-        ProfScope prof(K_COMPOSITE_FWD, (double)R * S * 16.0 + (double)R * 36.0);
-        rc = nerf_composite_forward(tr->mlp2->d_layer_output, tr->cfg.output_dim, tr->d_target, 3, nullptr, nullptr,
-                                    tr->d_pixel, tr->d_err, R, S);
-    }
-    if (rc != NERF_OK) return rc;
-    {
-        ProfScope prof(K_LOSS, (double)R * 12.0);
-        rc = nerf_loss_accumulate(tr->d_err, R, loss);
-    }
-    if (rc != NERF_OK) return rc;
-    {
-        ProfScope prof(K_COMPOSITE_BWD, (double)R * S * 32.0 + (double)R * 12.0);
-        rc = nerf_composite_backward(tr->mlp2->d_layer_output, tr->cfg.output_dim, tr->d_err,
-                                     tr->mlp2->d_error_output, R, S);
-    }
+    const int rc = composite_and_gradient(tr, tr->mlp2->d_layer_output, tr->mlp2->d_error_output, accumulate);
     if (rc != NERF_OK) return rc;
     mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp2->input_dim, tr->mlp1->d_error_output, accumulate);
     mlp_backward(tr->mlp1, tr->d_pe, tr->pe_ld, nullptr, accumulate);
@@ -172,6 +161,7 @@ void nerf_trainer_default_config(NerfTrainerConfig* cfg) {
     cfg->output_dim = NERF_DEFAULT_OUTPUT_DIM;
     cfg->learning_rate = NERF_DEFAULT_LR;
     cfg->precision = NERF_PRECISION_F32;
+    cfg->quadrature = NERF_QUADRATURE_REFERENCE;
 }
 
 size_t nerf_trainer_param_count(const NerfTrainerConfig* c) {
@@ -186,6 +176,7 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
         return nullptr;
     if ((long long)cfg->rays_per_batch * cfg->num_samples > 0x7fffffffLL) return nullptr;
     if (cfg->precision != NERF_PRECISION_F32 && cfg->precision != NERF_PRECISION_BF16) return nullptr;
+    if (cfg->quadrature != NERF_QUADRATURE_REFERENCE && cfg->quadrature != NERF_QUADRATURE_SPACING) return nullptr;
     const bool bf16 = cfg->precision == NERF_PRECISION_BF16;
     if (bf16 && !bf16_step_supported(NERF_PE_DIM3(cfg->pos_enc_l) + NERF_PE_DIM3(cfg->dir_enc_l), cfg->hidden_dim,
                                      cfg->intermediate_dim, cfg->output_dim))
@@ -313,6 +304,7 @@ static int forward_backward_impl(NerfTrainer* tr, const NerfDeviceDataset* datas
                                  const float* d_offsets, int accumulate) {
     if (!tr || !dataset || !d_idx) return NERF_ERR_ARG;
     const NerfTrainerConfig& c = tr->cfg;
+    tr->d_offsets_last = d_offsets;
     int rc;
     {
         ProfScope prof(K_ENCODE, (double)c.rays_per_batch * c.num_samples * tr->pe_dim * (tr->bf ? 2.0 : 4.0));
@@ -340,6 +332,7 @@ int nerf_trainer_forward_backward_add(NerfTrainer* tr, const NerfDeviceDataset* 
 int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X, const float* d_target) {
     if (!tr || !d_batch_X || !d_target) return NERF_ERR_ARG;
     if (tr->bf) return NERF_ERR_ARG;  // host-supplied samples are an fp32-path facility
+    if (tr->cfg.quadrature != NERF_QUADRATURE_REFERENCE) return NERF_ERR_ARG;  // the spacing needs the depths, not points
     const NerfTrainerConfig& c = tr->cfg;
     const int N = c.rays_per_batch * c.num_samples;
     int rc;

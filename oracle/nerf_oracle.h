@@ -56,6 +56,13 @@ void orc_composite_gradient_literal(const float* dens, const float* rgb, const f
                                     int S);
 void orc_composite_gradient_scan(const float* dens, const float* rgb, const float* err, float* d_out, int R,
                                  int S);
+/* opt-in quadrature with the true sample spacing (not the reference's arithmetic; see the .c file).
+ * The gradient accumulates in double: it is the arbiter for the fp32 device kernel. */
+void orc_composite_spacing(const float* dens, const float* rgb, const float* target, const float* offsets,
+                           float near_plane, float far_plane, float* pixel, float* err, float* loss_accum, int R,
+                           int S);
+void orc_composite_spacing_gradient(const float* dens, const float* rgb, const float* err, const float* offsets,
+                                    float near_plane, float far_plane, float* d_out, int R, int S);
 /* render quantisation: (unsigned char)(fminf(1, fmaxf(0, c)) * 255) */
 void orc_quantize_rgb(const float* pixel, uint8_t* out, int n);
 

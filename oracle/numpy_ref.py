@@ -132,6 +132,43 @@ def composite_gradient_closed(dens, rgb, err, R, S):
     return out.reshape(R * S, 4)
 
 
+LAST_DELTA = 1e10  # include/nerf_spec.h NERF_LAST_DELTA
+
+
+def depths(S, near, far, offsets=None):
+    """float32 depths exactly as sample_points evaluates them (offsets in units of one spacing)"""
+    near, far = f32(near), f32(far)
+    out = np.empty(S, f32)
+    for s in range(S):
+        fs = f32(s) if offsets is None else f32(s) + f32(offsets[s])
+        out[s] = near + (far - near) * fs / f32(S - 1)
+    return out
+
+
+def spacing_render(sigma, colour, t):
+    """Opt-in quadrature (NOT the reference's): delta_s = t_{s+1} - t_s, last = LAST_DELTA, no early
+    stop.  One ray, float64.  Returns the pixel and the per-sample weights."""
+    delta = np.append(np.diff(np.asarray(t, np.float64)), LAST_DELTA)
+    alpha = 1.0 - np.exp(-np.asarray(sigma, np.float64) * delta)
+    T = np.concatenate([[1.0], np.cumprod(1.0 - alpha)[:-1]])
+    w = T * alpha
+    return w @ np.asarray(colour, np.float64), w, alpha, T, delta
+
+
+def spacing_gradient(sigma, colour, err, t):
+    """analytic gradient of 1/2 |pixel - target|^2 w.r.t. (density, colour pre-sigmoid) per sample:
+    dL/dsigma_s = delta_s ((1 - alpha_s) T_s q_s - sum_{t>s} w_t q_t); relu' applied by the caller's sigma > 0"""
+    _, w, alpha, T, delta = spacing_render(sigma, colour, t)
+    colour = np.asarray(colour, np.float64)
+    q = colour @ np.asarray(err, np.float64)
+    wq = w * q
+    tail = np.concatenate([np.cumsum(wq[::-1])[::-1][1:], [0.0]])
+    g = np.zeros((len(w), 4))
+    g[:, 0] = np.where(np.asarray(sigma) > 0, delta * ((1.0 - alpha) * T * q - tail), 0.0)
+    g[:, 1:] = w[:, None] * np.asarray(err, np.float64)[None, :] * colour * (1.0 - colour)
+    return g
+
+
 def swish(x):
     return x / (1.0 + np.exp(-x))
 

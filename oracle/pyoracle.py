@@ -87,6 +87,8 @@ class Oracle:
         L.orc_composite_and_loss.argtypes = [FP, FP, FP, FP, FP, FP, C.c_int, C.c_int, FP]
         L.orc_composite_gradient_literal.argtypes = [FP, FP, FP, FP, C.c_int, C.c_int]
         L.orc_composite_gradient_scan.argtypes = [FP, FP, FP, FP, C.c_int, C.c_int]
+        L.orc_composite_spacing.argtypes = [FP, FP, FP, FP, C.c_float, C.c_float, FP, FP, FP, C.c_int, C.c_int]
+        L.orc_composite_spacing_gradient.argtypes = [FP, FP, FP, FP, C.c_float, C.c_float, FP, C.c_int, C.c_int]
         L.orc_quantize_rgb.argtypes = [FP, C.POINTER(C.c_uint8), C.c_int]
         L.orc_fill_weights.argtypes = [FP, C.c_int, C.c_int, C.c_uint64]
         L.orc_adamw_scalars.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, FP, FP]
@@ -164,6 +166,29 @@ class Oracle:
         out = np.empty((R * S, 4), np.float32)
         fn = self.lib.orc_composite_gradient_literal if literal else self.lib.orc_composite_gradient_scan
         fn(_fp(dens), _fp(rgb), _fp(err), _fp(out), R, S)
+        return out
+
+    def composite_spacing(self, dens, rgb, target_rep, R, S, near, far, offsets=None):
+        """opt-in quadrature with the true sample spacing: pixel, err, loss_sum"""
+        dens = np.ascontiguousarray(dens, np.float32)
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        target_rep = np.ascontiguousarray(target_rep, np.float32)
+        off = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        pixel = np.empty((R, 3), np.float32)
+        err = np.empty((R, 3), np.float32)
+        loss = np.zeros(1, np.float32)
+        self.lib.orc_composite_spacing(_fp(dens), _fp(rgb), _fp(target_rep), _fp(off) if off is not None else None,
+                                       near, far, _fp(pixel), _fp(err), _fp(loss), R, S)
+        return pixel, err, float(loss[0])
+
+    def composite_spacing_gradient(self, dens, rgb, err, R, S, near, far, offsets=None):
+        dens = np.ascontiguousarray(dens, np.float32)
+        rgb = np.ascontiguousarray(rgb, np.float32)
+        err = np.ascontiguousarray(err, np.float32)
+        off = None if offsets is None else np.ascontiguousarray(offsets, np.float32)
+        out = np.empty((R * S, 4), np.float32)
+        self.lib.orc_composite_spacing_gradient(_fp(dens), _fp(rgb), _fp(err), _fp(off) if off is not None else None,
+                                                near, far, _fp(out), R, S)
         return out
 
     def quantize(self, pixel):
