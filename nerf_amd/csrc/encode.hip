@@ -104,74 +104,90 @@ __device__ __forceinline__ void put(float* base, size_t index, float v) {
     }
 }
 
+// A workgroup owns ENC_POINTS consecutive points.  Phase 1: one thread per point builds the sample
+// (ray through the pixel, depth, position) once and parks position and direction in LDS.  Phase 2:
+// the 256 threads walk the (point, slot) items of those points -- slot = one identity triple or one
+// (octave, coordinate) sin/cos pair -- so that a wavefront's stores run along an encoding row.
+constexpr int ENC_POINTS = 64;
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a) {
-    const int pos_w = NERF_PE_DIM3(a.pos_l);
-    // without an encoding buffer only the raw samples are wanted: one work item per point
-    const int slots_pos = 1 + 3 * a.pos_l, slots = a.pe ? slots_pos + 1 + 3 * a.dir_l : 1;
-    const long long total = (long long)a.R * a.S * slots;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
-    const long long point = gid / slots;
-    const int slot = (int)(gid - point * slots);
-    const int ray = (int)(point / a.S), s = (int)(point - (long long)ray * a.S);
-
-    float pos[3], dir[3];
-    if (a.source == SRC_POINTS) {
-        const float* x = a.batch_X + point * 6;
-        pos[0] = x[0]; pos[1] = x[1]; pos[2] = x[2];
-        dir[0] = x[3]; dir[1] = x[4]; dir[2] = x[5];
-    } else {
-        float o[3];
-        if (a.source == SRC_INDICES) {
-            const int img = a.idx[3 * ray + 0], u = a.idx[3 * ray + 1], v = a.idx[3 * ray + 2];
-            const DeviceCamera cam = a.cams[img];
-            ray_through_pixel(cam, u, v, o, dir);
-            if (a.target && s == 0 && slot == 0) {
-                // nerf.c:176-179: RGBA pixel, alpha ignored, byte / 255.0f
-                const unsigned char* px = a.pixels + a.img_off[img] + ((size_t)v * cam.width + u) * 4;
-#pragma unroll
-                for (int c = 0; c < 3; c++) a.target[ray * 3 + c] = __fdiv_rn((float)px[c], 255.0f);
-            }
+    __shared__ float sample[ENC_POINTS][6];
+    const long long n_points = (long long)a.R * a.S;
+    const long long p0 = (long long)blockIdx.x * ENC_POINTS;
+    if (threadIdx.x < ENC_POINTS && p0 + threadIdx.x < n_points) {
+        const long long point = p0 + threadIdx.x;
+        const int ray = (int)(point / a.S), s = (int)(point - (long long)ray * a.S);
+        float pos[3], dir[3];
+        if (a.source == SRC_POINTS) {
+            const float* x = a.batch_X + point * 6;
+            pos[0] = x[0]; pos[1] = x[1]; pos[2] = x[2];
+            dir[0] = x[3]; dir[1] = x[4]; dir[2] = x[5];
         } else {
-            // nerf.c:262-266: render pixel -> dataset-resolution pixel, truncating
-            const int pix = a.first_pixel + ray;
-            const int rv = pix / a.render_w, ru = pix - rv * a.render_w;
-            const int su = (int)__fdiv_rn(__fmul_rn((float)ru, (float)a.view.width), (float)a.render_w);
-            const int sv = (int)__fdiv_rn(__fmul_rn((float)rv, (float)a.view.height), (float)a.render_h);
-            ray_through_pixel(a.view, su, sv, o, dir);
-        }
-        const float off = a.offsets ? a.offsets[(size_t)ray * a.S + s] : 0.0f;
-        const float t = sample_depth(s, a.S, a.near_plane, a.far_plane, off);
+            float o[3];
+            if (a.source == SRC_INDICES) {
+                const int img = a.idx[3 * ray + 0], u = a.idx[3 * ray + 1], v = a.idx[3 * ray + 2];
+                const DeviceCamera cam = a.cams[img];
+                ray_through_pixel(cam, u, v, o, dir);
+                if (a.target && s == 0) {
+                    // nerf.c:176-179: RGBA pixel, alpha ignored, byte / 255.0f
+                    const unsigned char* px = a.pixels + a.img_off[img] + ((size_t)v * cam.width + u) * 4;
 #pragma unroll
-        for (int c = 0; c < 3; c++) pos[c] = __fadd_rn(o[c], __fmul_rn(t, dir[c]));  // nerf.c:191-193
-    }
-
-    if (a.batch_X_out && slot == 0) {
-        float* x = a.batch_X_out + point * 6;
-        x[0] = pos[0]; x[1] = pos[1]; x[2] = pos[2];
-        x[3] = dir[0]; x[4] = dir[1]; x[5] = dir[2];
+                    for (int c = 0; c < 3; c++) a.target[ray * 3 + c] = __fdiv_rn((float)px[c], 255.0f);
+                }
+            } else {
+                // nerf.c:262-266: render pixel -> dataset-resolution pixel, truncating
+                const int pix = a.first_pixel + ray;
+                const int rv = pix / a.render_w, ru = pix - rv * a.render_w;
+                const int su = (int)__fdiv_rn(__fmul_rn((float)ru, (float)a.view.width), (float)a.render_w);
+                const int sv = (int)__fdiv_rn(__fmul_rn((float)rv, (float)a.view.height), (float)a.render_h);
+                ray_through_pixel(a.view, su, sv, o, dir);
+            }
+            const float off = a.offsets ? a.offsets[(size_t)ray * a.S + s] : 0.0f;
+            const float t = sample_depth(s, a.S, a.near_plane, a.far_plane, off);
+#pragma unroll
+            for (int c = 0; c < 3; c++) pos[c] = __fadd_rn(o[c], __fmul_rn(t, dir[c]));  // nerf.c:191-193
+        }
+        if (a.batch_X_out) {
+            float* x = a.batch_X_out + point * 6;
+            x[0] = pos[0]; x[1] = pos[1]; x[2] = pos[2];
+            x[3] = dir[0]; x[4] = dir[1]; x[5] = dir[2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            sample[threadIdx.x][c] = pos[c];
+            sample[threadIdx.x][3 + c] = dir[c];
+        }
     }
     if (!a.pe) return;
-    const size_t row = (size_t)point * a.ld_pe;
-    if (slot == 0) {
-        put<BF16>(a.pe, row + 0, pos[0]); put<BF16>(a.pe, row + 1, pos[1]); put<BF16>(a.pe, row + 2, pos[2]);
-    } else if (slot == slots_pos) {
-        put<BF16>(a.pe, row + pos_w + 0, dir[0]); put<BF16>(a.pe, row + pos_w + 1, dir[1]);
-        put<BF16>(a.pe, row + pos_w + 2, dir[2]);
-    } else {
-        const bool is_dir = slot > slots_pos;
-        const int k = is_dir ? slot - slots_pos - 1 : slot - 1;
-        const int l = k / 3, i = k - 3 * l;
-        const float x = is_dir ? (i == 0 ? dir[0] : (i == 1 ? dir[1] : dir[2]))
-                               : (i == 0 ? pos[0] : (i == 1 ? pos[1] : pos[2]));
-        const double freq = (double)(1u << l);  // powf(2, l) is exact for these l
-        const float arg = (float)(__dmul_rn(__dmul_rn(freq, 3.14159265358979323846), (double)x));
-        float sv, cv;
-        sincosf(arg, &sv, &cv);
-        const size_t dst = row + (is_dir ? pos_w : 0) + 3 + 6 * l + 2 * i;
-        put<BF16>(a.pe, dst, sv);
-        put<BF16>(a.pe, dst + 1, cv);
+    __syncthreads();
+
+    const int pos_w = NERF_PE_DIM3(a.pos_l);
+    const int slots_pos = 1 + 3 * a.pos_l, slots = slots_pos + 1 + 3 * a.dir_l;
+    const long long left = n_points - p0;
+    const int here = left < ENC_POINTS ? (int)left : ENC_POINTS;
+    for (int item = threadIdx.x; item < here * slots; item += 256) {
+        const int pt = item / slots, slot = item - pt * slots;
+        const float* v = sample[pt];
+        const size_t row = (size_t)(p0 + pt) * a.ld_pe;
+        if (slot == 0) {
+            put<BF16>(a.pe, row + 0, v[0]); put<BF16>(a.pe, row + 1, v[1]); put<BF16>(a.pe, row + 2, v[2]);
+        } else if (slot == slots_pos) {
+            put<BF16>(a.pe, row + pos_w + 0, v[3]); put<BF16>(a.pe, row + pos_w + 1, v[4]);
+            put<BF16>(a.pe, row + pos_w + 2, v[5]);
+        } else {
+            const bool is_dir = slot > slots_pos;
+            const int k = is_dir ? slot - slots_pos - 1 : slot - 1;
+            const int l = k / 3, i = k - 3 * l;
+            const float x = v[(is_dir ? 3 : 0) + i];
+            const double freq = (double)(1u << l);  // powf(2, l) is exact for these l
+            const float arg = (float)(__dmul_rn(__dmul_rn(freq, 3.14159265358979323846), (double)x));
+            float sv, cv;
+            sincosf(arg, &sv, &cv);
+            const size_t dst = row + (is_dir ? pos_w : 0) + 3 + 6 * l + 2 * i;
+            put<BF16>(a.pe, dst, sv);
+            put<BF16>(a.pe, dst + 1, cv);
+        }
     }
 }
 
@@ -195,9 +211,7 @@ int launch_encode(const EncodeArgs& a) {
         a.pos_l > 30 || a.dir_l > 30 || (!a.pe && !a.batch_X_out))
         return NERF_ERR_ARG;
     if (a.pe && a.ld_pe < NERF_PE_DIM3(a.pos_l) + NERF_PE_DIM3(a.dir_l)) return NERF_ERR_ARG;
-    const long long slots = a.pe ? 2 + 3 * (a.pos_l + a.dir_l) : 1;
-    const long long total = (long long)a.R * a.S * slots;
-    const long long grid = (total + 255) / 256;
+    const long long grid = ((long long)a.R * a.S + ENC_POINTS - 1) / ENC_POINTS;
     if (grid > 0x7fffffffLL) return NERF_ERR_ARG;
     if (a.pe_bf16)
         hipLaunchKernelGGL(encode_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
