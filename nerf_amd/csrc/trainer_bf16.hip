@@ -41,7 +41,10 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
-// raw[n][o] = sum_h act[n][h] * bf16(W2[o][h]): 16 lanes per point, 8 features per lane and step
+// raw[n][o] = sum_h act[n][h] * bf16(W2[o][h]).  A 16-lane group takes HEAD_ROWS points at a time, 8
+// features per lane and step, so every weight read from LDS is used HEAD_ROWS times.
+constexpr int HEAD_ROWS = 4;
+
 template <int OUT>
 __global__ __launch_bounds__(256) void head_forward_bf16_kernel(const bf16_t* __restrict__ act,
                                                                 const float* __restrict__ W2, float* __restrict__ Y,
@@ -50,30 +53,44 @@ __global__ __launch_bounds__(256) void head_forward_bf16_kernel(const bf16_t* __
     for (int i = threadIdx.x; i < OUT * hidden; i += 256) w2s[i] = bf16_round(W2[i]);
     __syncthreads();
     const int sub = threadIdx.x & 15;
-    const long rows_per_iter = (long)gridDim.x * 16;
-    for (long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4); row < rows; row += rows_per_iter) {
-        const bf16_t* h = act + row * hidden;
-        float acc[OUT];
+    const long rows_per_iter = (long)gridDim.x * 16 * HEAD_ROWS;
+    for (long row0 = ((long)blockIdx.x * 16 + (threadIdx.x >> 4)) * HEAD_ROWS; row0 < rows; row0 += rows_per_iter) {
+        float acc[HEAD_ROWS][OUT];
 #pragma unroll
-        for (int o = 0; o < OUT; o++) acc[o] = 0.f;
+        for (int r = 0; r < HEAD_ROWS; r++)
+#pragma unroll
+            for (int o = 0; o < OUT; o++) acc[r][o] = 0.f;
         for (int c = sub * 8; c < hidden; c += 128) {
-            float x[8];
-            unpack8(*reinterpret_cast<const u32x4*>(h + c), x);
+            float x[HEAD_ROWS][8];
+#pragma unroll
+            for (int r = 0; r < HEAD_ROWS; r++) {
+                const long row = row0 + r < rows ? row0 + r : rows - 1;  // clamp: the extra rows are not stored
+                unpack8(*reinterpret_cast<const u32x4*>(act + row * hidden + c), x[r]);
+            }
 #pragma unroll
             for (int o = 0; o < OUT; o++) {
-                const float* w = w2s + o * hidden + c;
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(w2s + o * hidden + c);
+                const f32x4 wb = *reinterpret_cast<const f32x4*>(w2s + o * hidden + c + 4);
 #pragma unroll
-                for (int k = 0; k < 8; k++) acc[o] += x[k] * w[k];
+                for (int r = 0; r < HEAD_ROWS; r++)
+                    acc[r][o] += x[r][0] * wa[0] + x[r][1] * wa[1] + x[r][2] * wa[2] + x[r][3] * wa[3] +
+                                 x[r][4] * wb[0] + x[r][5] * wb[1] + x[r][6] * wb[2] + x[r][7] * wb[3];
             }
         }
 #pragma unroll
-        for (int o = 0; o < OUT; o++) {
+        for (int r = 0; r < HEAD_ROWS; r++)
 #pragma unroll
-            for (int d = 8; d >= 1; d >>= 1) acc[o] += __shfl_xor(acc[o], d, 64);
-        }
+            for (int o = 0; o < OUT; o++) {
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) acc[r][o] += __shfl_xor(acc[r][o], d, 64);
+            }
         if (sub == 0) {
 #pragma unroll
-            for (int o = 0; o < OUT; o++) Y[row * OUT + o] = acc[o];
+            for (int r = 0; r < HEAD_ROWS; r++)
+                if (row0 + r < rows) {
+#pragma unroll
+                    for (int o = 0; o < OUT; o++) Y[(row0 + r) * OUT + o] = acc[r][o];
+                }
         }
     }
 }
@@ -110,9 +127,9 @@ __global__ __launch_bounds__(256) void head_backward_bf16_kernel(const float* __
         float eh[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const float den = 1.0f + expf(-x[k]);
-            const float sg = 1.0f / den;
-            const float hact = x[k] / den;
+            // hardware exp2/rcp (about 1 ulp each): far inside bf16's 8 bits
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x[k] * -1.44269504088896340736f));
+            const float hact = x[k] * sg;
             const float d = sg + x[k] * sg * (1.0f - sg);
             float back = e[0] * w2[0][k];
 #pragma unroll
@@ -234,8 +251,9 @@ int bf16_step_forward(Bf16Step* st, const float* W2b) {
     if (rc == NERF_OK) rc = nt(st->y1, M, st->w1b, M, st->pre2, st->act2, nullptr, H, N, H, M, EPI_SWISH, K_GEMM_FWD);
     if (rc != NERF_OK) return rc;
     ProfScope prof(K_SKINNY_FWD, (double)N * (H * 2.0 + O * 4.0));
-    long blocks = (N + 127) / 128;
+    long blocks = (N + 16 * HEAD_ROWS * 8 - 1) / (16 * HEAD_ROWS * 8);  // 8 sweeps per workgroup
     if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((head_forward_bf16_kernel<4>), dim3((unsigned)blocks), dim3(256), (size_t)O * H * sizeof(float),
                        stream(), st->act2, W2b, st->raw, N, H);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
