@@ -44,6 +44,11 @@ struct NtArgs {
     int tiles_m, tiles_n;
 };
 
+// Two shapes of every kernel: four wavefronts 2x2 with 2x2 MFMA tiles each (128x128 output tile,
+// two workgroups per CU) and eight wavefronts 2x4 with 4x2 MFMA tiles each (256x256 output tile, one
+// workgroup per CU).  At bf16 rates the 128x128 shape is bound by LDS traffic (one 16-byte fragment
+// read per MFMA); the large shape reads 0.75 fragments per MFMA and stages half the bytes per MFMA.
+
 // ================================================================================================
 // C = A B^T, k-contiguous operands
 // ================================================================================================
@@ -55,48 +60,49 @@ __device__ __forceinline__ bf16x8 kc_frag(const float* __restrict__ T, int rb, i
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int CUR>
-__device__ __forceinline__ void nt_tile(float (&lds)[2][2 * 128 * BK], const DmaLoader<true, 128>& da,
-                                        const DmaLoader<true, 128>& db, f32x16 (&acc)[2][2], int next, int wave,
-                                        int wm, int wn, int lane) {
-    constexpr int TILE = 128 * BK;
+template <int WM, int WN, int MI, int NI, int CUR>
+__device__ __forceinline__ void nt_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 * BK],
+                                        const DmaLoader<true, WM * MI * 32, WM * WN * 64>& da,
+                                        const DmaLoader<true, WN * NI * 32, WM * WN * 64>& db, f32x16 (&acc)[NI][MI],
+                                        int next, int wave, int wm, int wn, int lane) {
+    constexpr int XTILE = WM * MI * 32 * BK;
     da.issue(lds[CUR ^ 1], next, wave);
-    db.issue(lds[CUR ^ 1] + TILE, next, wave);
-    const float* TX = lds[CUR];         // points (m)
-    const float* TW = lds[CUR] + TILE;  // weights (n)
-    bf16x8 fx[2][2], fw[2][2];
+    db.issue(lds[CUR ^ 1] + XTILE, next, wave);
+    const float* TX = lds[CUR];          // points (m)
+    const float* TW = lds[CUR] + XTILE;  // weights (n)
+    bf16x8 fx[2][MI], fw[2][NI];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        fx[0][i] = kc_frag(TX, wm * 64 + i * 32, 0, lane);
-        fw[0][i] = kc_frag(TW, wn * 64 + i * 32, 0, lane);
-    }
+    for (int i = 0; i < MI; i++) fx[0][i] = kc_frag(TX, (wm * MI + i) * 32, 0, lane);
+#pragma unroll
+    for (int i = 0; i < NI; i++) fw[0][i] = kc_frag(TW, (wn * NI + i) * 32, 0, lane);
 #pragma unroll
     for (int s = 0; s < BKH / 16; s++) {
         const int c = s & 1, n = c ^ 1;
         if (s + 1 < BKH / 16) {
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                fx[n][i] = kc_frag(TX, wm * 64 + i * 32, s + 1, lane);
-                fw[n][i] = kc_frag(TW, wn * 64 + i * 32, s + 1, lane);
-            }
+            for (int i = 0; i < MI; i++) fx[n][i] = kc_frag(TX, (wm * MI + i) * 32, s + 1, lane);
+#pragma unroll
+            for (int i = 0; i < NI; i++) fw[n][i] = kc_frag(TW, (wn * NI + i) * 32, s + 1, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
         // weights are the row operand: acc[ni][mi] has the feature n in its registers, the point m on its lanes
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++)
+        for (int ni = 0; ni < NI; ni++)
 #pragma unroll
-            for (int mi = 0; mi < 2; mi++)
+            for (int mi = 0; mi < MI; mi++)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[c][ni], fx[c][mi], acc[ni][mi], 0, 0, 0);
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const NtArgs ka) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2 * 128 * BK];
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(WM * WN * 64, 512 / (WM * WN * 64)) void gemm_bf16_nt_kernel(const NtArgs ka) {
+    constexpr int NTH = WM * WN * 64, BM_ = WM * MI * 32, BN_ = WN * NI * 32;
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM_ + BN_) * BK];
     const GemmBf16Args& p = ka.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // XCD-aware order: the n-tiles of one row panel of A run back to back on one XCD
     int tm, tn;
     {
@@ -110,35 +116,35 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const NtArgs ka) {
             tm = b / ka.tiles_n;
         }
     }
-    const int m0 = tm * 128, n0 = tn * 128;
+    const int m0 = tm * BM_, n0 = tn * BN_;
     const int nkt = p.K / BKH;
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][MI];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < NI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < MI; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     // the loader works in 4-byte units: a bf16 row of K elements is K/2 of them
-    const DmaLoader<true, 128> da(reinterpret_cast<const float*>(p.A), p.lda / 2, m0, p.M, p.K / 2, 0, tid);
-    const DmaLoader<true, 128> db(reinterpret_cast<const float*>(p.B), p.ldb / 2, n0, p.N, p.K / 2, 0, tid);
+    const DmaLoader<true, BM_, NTH> da(reinterpret_cast<const float*>(p.A), p.lda / 2, m0, p.M, p.K / 2, 0, tid);
+    const DmaLoader<true, BN_, NTH> db(reinterpret_cast<const float*>(p.B), p.ldb / 2, n0, p.N, p.K / 2, 0, tid);
     if (nkt > 0) {
         da.issue(lds[0], 0, wave);
-        db.issue(lds[0] + 128 * BK, 0, wave);
+        db.issue(lds[0] + BM_ * BK, 0, wave);
     }
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nkt; kt += 2) {
-        nt_tile<0>(lds, da, db, acc, kt + 1, wave, wm, wn, lane);
-        nt_tile<1>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, wm, wn, lane);
+        nt_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt + 1, wave, wm, wn, lane);
+        nt_tile<WM, WN, MI, NI, 1>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, wm, wn, lane);
     }
-    if (kt < nkt) nt_tile<0>(lds, da, db, acc, kt, wave, wm, wn, lane);
+    if (kt < nkt) nt_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, wm, wn, lane);
 
     // ---- epilogue: lane owns point m = lane & 31 of each 32-point block and, per register group
     // q = r >> 2, the 4 consecutive features n = 8q + 4 (lane >> 5) + (0..3): 8 bytes of a bf16 row
-    const int rows_here = (p.M - m0) < 128 ? (p.M - m0) : 128;
+    const int rows_here = (p.M - m0) < BM_ ? (p.M - m0) : BM_;
     const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 2u;
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.C + (size_t)m0 * p.ldc), 0, p.C ? panel_bytes : 0u, 0x00020000);
@@ -147,11 +153,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const NtArgs ka) {
     const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((p.epilogue == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++) {
-        const int m_local = wm * 64 + mi * 32 + (lane & 31);
+    for (int mi = 0; mi < MI; mi++) {
+        const int m_local = (wm * MI + mi) * 32 + (lane & 31);
 #pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
-            const int n_first = n0 + wn * 64 + ni * 32 + 4 * (lane >> 5);
+        for (int ni = 0; ni < NI; ni++) {
+            const int n_first = n0 + (wn * NI + ni) * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int n = n_first + 8 * q;
@@ -188,10 +194,17 @@ struct WgArgs {
     int tiles_m, tiles_n;
 };
 
-// Row-major tile of 64 contraction rows x 128 columns (256-byte rows, 16 chunks of 16 bytes).
+// Row-major tile of 64 contraction rows x COLS columns (COLS/8 chunks of 16 bytes per row).  Within
+// each 256-byte half of a row, chunk c of row r sits at c ^ (((r & 3) << 2) | ((r >> 2) & 3)).
+__device__ __forceinline__ int row_swizzle(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <int COLS, int NTH>
 struct RowTileLoader {
+    static constexpr int CPR = COLS / 8;            // chunks per row
+    static constexpr int PASSES = BKH * CPR / NTH;  // 16-byte pieces per lane and tile
+    static_assert((BKH * CPR) % NTH == 0 && CPR % 16 == 0, "tile must split evenly over the workgroup");
     __amdgpu_buffer_rsrc_t rsrc;
-    unsigned voff[4];
+    unsigned voff[PASSES];
     unsigned tile_stride;
 
     __device__ __forceinline__ RowTileLoader(const bf16_t* base, int ld, int x0, int kbeg, int K, int tid) {
@@ -200,10 +213,10 @@ struct RowTileLoader {
         const size_t remaining = (size_t)(K - kbeg - 1) * ld + (ld - x0);
         tile_stride = (unsigned)(BKH * ld) * 2u;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int L = p * 256 + tid;
-            const int row = L >> 4;
-            const int chunk = (L & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        for (int p = 0; p < PASSES; p++) {
+            const int L = p * NTH + tid;
+            const int row = L / CPR, stored = L % CPR;
+            const int chunk = (stored & ~15) | ((stored & 15) ^ row_swizzle(row));
             voff[p] = (x0 + chunk * 8 + 8 <= ld) ? (unsigned)(row * ld + chunk * 8) * 2u : OOR;
         }
         const size_t bytes = remaining * 2;
@@ -211,120 +224,128 @@ struct RowTileLoader {
                                                  (unsigned)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
     }
 
-    __device__ __forceinline__ void issue(float* tile, int kt, int wave) const {
+    __device__ __forceinline__ void issue(char* tile, int kt, int wave) const {
         const unsigned soff = (unsigned)kt * tile_stride;
 #pragma unroll
-        for (int p = 0; p < 4; p++)
+        for (int p = 0; p < PASSES; p++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void*)(tile + (p * 256 + wave * 64) * 4), 16, voff[p], soff, 0, 0);
+                rsrc, (__attribute__((address_space(3))) void*)(tile + (p * NTH + wave * 64) * 16), 16, voff[p], soff, 0, 0);
     }
 };
 
 // Byte offset, inside a row-major tile, of this lane's address for the transposed read that yields
-// rows (contraction steps) 8 (lane >> 5) + 4 h2 + (0..3) of the first 16-step group, columns
-// 32 cb + (lane & 31)... as the MFMA operand map wants them: within a 16-lane group, lane 4q + p
+// rows (contraction steps) 8 (lane >> 5) + 4 h2 + (0..3) of the first 16-step group for the 32
+// columns of block cb, as the MFMA operand map wants them: within a 16-lane group, lane 4q + p
 // points at row q, columns 4p .. 4p+3 of the group's 16 columns.
+template <int COLS>
 __device__ __forceinline__ unsigned tr_lane_offset(int lane, int cb, int h2) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
     const int row = 8 * (g >> 1) + 4 * h2 + q;
     const int chunk = 4 * cb + 2 * (g & 1) + (pp >> 1);
-    const int f = ((row & 3) << 2) | ((row >> 2) & 3);
-    return (unsigned)(256 * row + 16 * (chunk ^ f) + 8 * (pp & 1));
+    return (unsigned)(COLS * 2 * row + 256 * (chunk >> 4) + 16 * ((chunk & 15) ^ row_swizzle(row)) + 8 * (pp & 1));
 }
 
+template <int COLS>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, unsigned off_lo, unsigned off_hi, int s) {
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tile + off_lo + 4096 * s));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tile + off_hi + 4096 * s));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tile + off_lo + 16 * COLS * 2 * s));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tile + off_hi + 16 * COLS * 2 * s));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int CUR>
-__device__ __forceinline__ void wg_tile(char (&lds)[2][2 * BKH * 256], const RowTileLoader& da, const RowTileLoader& db,
-                                        f32x16 (&acc)[2][2], int next, int wave, const unsigned (&offA)[2][2],
-                                        const unsigned (&offB)[2][2]) {
-    constexpr int TILE = BKH * 256;
-    da.issue(reinterpret_cast<float*>(lds[CUR ^ 1]), next, wave);
-    db.issue(reinterpret_cast<float*>(lds[CUR ^ 1] + TILE), next, wave);
+template <int WM, int WN, int MI, int NI, int CUR>
+__device__ __forceinline__ void wg_tile(char (&lds)[2][BKH * (WM * MI + WN * NI) * 64],
+                                        const RowTileLoader<WM * MI * 32, WM * WN * 64>& da,
+                                        const RowTileLoader<WN * NI * 32, WM * WN * 64>& db, f32x16 (&acc)[MI][NI],
+                                        int next, int wave, const unsigned (&offA)[MI][2], const unsigned (&offB)[NI][2]) {
+    constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32, ATILE = BKH * BM_ * 2;
+    da.issue(lds[CUR ^ 1], next, wave);
+    db.issue(lds[CUR ^ 1] + ATILE, next, wave);
     const char* TA = lds[CUR];
-    const char* TB = lds[CUR] + TILE;
-    bf16x8 fa[2][2], fb[2][2];
+    const char* TB = lds[CUR] + ATILE;
+    bf16x8 fa[2][MI], fb[2][NI];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        fa[0][i] = tr_frag(TA, offA[i][0], offA[i][1], 0);
-        fb[0][i] = tr_frag(TB, offB[i][0], offB[i][1], 0);
-    }
+    for (int i = 0; i < MI; i++) fa[0][i] = tr_frag<BM_>(TA, offA[i][0], offA[i][1], 0);
+#pragma unroll
+    for (int i = 0; i < NI; i++) fb[0][i] = tr_frag<BN_>(TB, offB[i][0], offB[i][1], 0);
 #pragma unroll
     for (int s = 0; s < BKH / 16; s++) {
         const int c = s & 1, n = c ^ 1;
         if (s + 1 < BKH / 16) {
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                fa[n][i] = tr_frag(TA, offA[i][0], offA[i][1], s + 1);
-                fb[n][i] = tr_frag(TB, offB[i][0], offB[i][1], s + 1);
-            }
+            for (int i = 0; i < MI; i++) fa[n][i] = tr_frag<BM_>(TA, offA[i][0], offA[i][1], s + 1);
+#pragma unroll
+            for (int i = 0; i < NI; i++) fb[n][i] = tr_frag<BN_>(TB, offB[i][0], offB[i][1], s + 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mi = 0; mi < 2; mi++)
+        for (int mi = 0; mi < MI; mi++)
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++)
+            for (int ni = 0; ni < NI; ni++)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][mi], fb[c][ni], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgArgs wa) {
-    __shared__ __attribute__((aligned(16))) char lds[2][2 * BKH * 256];
+template <int WM, int WN, int MI, int NI>
+__global__ __launch_bounds__(WM * WN * 64, 512 / (WM * WN * 64)) void wgrad_bf16_kernel(const WgArgs wa) {
+    constexpr int NTH = WM * WN * 64, BM_ = WM * MI * 32, BN_ = WN * NI * 32;
+    __shared__ __attribute__((aligned(16))) char lds[2][BKH * (BM_ + BN_) * 2];
     const GemmArgs& p = wa.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     KernelArgs ka;
     ka.g = p;
     ka.tiles_m = wa.tiles_m;
     ka.tiles_n = wa.tiles_n;
     int tm, tn, split;
     decode_block(ka, blockIdx.x, tm, tn, split);
-    const int m0 = tm * 128, n0 = tn * 128;
+    const int m0 = tm * BM_, n0 = tn * BN_;
     const int kbeg = split * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
     const int nkt = kend > kbeg ? (kend - kbeg + BKH - 1) / BKH : 0;  // rows past K read as zero
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < NI; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    unsigned offA[2][2], offB[2][2];
+    unsigned offA[MI][2], offB[NI][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int h2 = 0; h2 < 2; h2++) {
 #pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-            offA[i][h2] = tr_lane_offset(lane, wm * 2 + i, h2);
-            offB[i][h2] = tr_lane_offset(lane, wn * 2 + i, h2);
-        }
+        for (int i = 0; i < MI; i++) offA[i][h2] = tr_lane_offset<BM_>(lane, wm * MI + i, h2);
+#pragma unroll
+        for (int i = 0; i < NI; i++) offB[i][h2] = tr_lane_offset<BN_>(lane, wn * NI + i, h2);
+    }
 
-    const RowTileLoader da(wa.err, wa.ld_err, m0, kbeg, kend, tid);
-    const RowTileLoader db(wa.act, wa.ld_act, n0, kbeg, kend, tid);
+    const RowTileLoader<BM_, NTH> da(wa.err, wa.ld_err, m0, kbeg, kend, tid);
+    const RowTileLoader<BN_, NTH> db(wa.act, wa.ld_act, n0, kbeg, kend, tid);
     if (nkt > 0) {
-        da.issue(reinterpret_cast<float*>(lds[0]), 0, wave);
-        db.issue(reinterpret_cast<float*>(lds[0] + BKH * 256), 0, wave);
+        da.issue(lds[0], 0, wave);
+        db.issue(lds[0] + BKH * BM_ * 2, 0, wave);
     }
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nkt; kt += 2) {
-        wg_tile<0>(lds, da, db, acc, kt + 1, wave, offA, offB);
-        wg_tile<1>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, offA, offB);
+        wg_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt + 1, wave, offA, offB);
+        wg_tile<WM, WN, MI, NI, 1>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, offA, offB);
     }
-    if (kt < nkt) wg_tile<0>(lds, da, db, acc, kt, wave, offA, offB);
-    epilogue<2, 2>(p, acc, m0, n0, split, wm * 64, wn * 64, lane);
+    if (kt < nkt) wg_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, offA, offB);
+    epilogue<MI, NI>(p, acc, m0, n0, split, wm * MI * 32, wn * NI * 32, lane, BM_);
 }
+
+// explicit instantiations of the two shapes
+template __global__ void gemm_bf16_nt_kernel<2, 2, 2, 2>(const NtArgs);
+template __global__ void gemm_bf16_nt_kernel<2, 4, 4, 2>(const NtArgs);
+template __global__ void wgrad_bf16_kernel<2, 2, 2, 2>(const WgArgs);
+template __global__ void wgrad_bf16_kernel<2, 4, 4, 2>(const WgArgs);
 
 // fp32 -> bf16 (round to nearest even), optionally into a wider pitch with a zero tail, optionally transposed
 __global__ __launch_bounds__(256) void convert_bf16_kernel(const float* __restrict__ src, int rows, int cols, int ld_src,
@@ -352,23 +373,31 @@ int gemm_bf16_nt(const GemmBf16Args& g) {
         (reinterpret_cast<uintptr_t>(g.C2) & 7) || (reinterpret_cast<uintptr_t>(g.AUX) & 7))
         return NERF_ERR_ARG;
     if (g.epilogue != EPI_STORE && g.epilogue != EPI_SWISH && g.epilogue != EPI_DSWISH_MUL) return NERF_ERR_ARG;
-    if ((long long)128 * g.ldc * 2 > 0x7fffffffLL) return NERF_ERR_ARG;
     NtArgs ka;
     ka.g = g;
-    ka.tiles_m = (g.M + 127) / 128;
-    ka.tiles_n = (g.N + 127) / 128;
+    // the 256x256 shape when the product is large enough to fill the chip with it
+    const bool big = g.N > 128 && (long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 256;
+    const int tile = big ? 256 : 128;
+    if ((long long)tile * g.ldc * 2 > 0x7fffffffLL) return NERF_ERR_ARG;
+    ka.tiles_m = (g.M + tile - 1) / tile;
+    ka.tiles_n = (g.N + tile - 1) / tile;
     const long grid = (long)ka.tiles_m * ka.tiles_n;
     if (grid > 0x7fffffffL) return NERF_ERR_ARG;
-    hipLaunchKernelGGL(gemm_bf16_nt_kernel, dim3((unsigned)grid), dim3(256), 0, stream(), ka);
+    if (big)
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 4, 4, 2>), dim3((unsigned)grid), dim3(512), 0, stream(), ka);
+    else
+        hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, stream(), ka);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
 WgradPlan plan_weight_gradient_bf16(int rows_out, int cols, long batch) {
     WgradPlan pl;
-    pl.tile_n = 128;
-    const int tiles = ((rows_out + 127) / 128) * ((cols + 127) / 128);
+    // 256x256 output tiles (one 512-thread workgroup per CU) when both extents are past one 128 tile
+    pl.tile_n = (rows_out > 128 && cols > 128) ? 256 : 128;
+    const int tiles = ((rows_out + pl.tile_n - 1) / pl.tile_n) * ((cols + pl.tile_n - 1) / pl.tile_n);
+    const int want = pl.tile_n == 256 ? 256 : 512;  // workgroups in flight that fill the chip
     // as choose_splits, with K-tiles of 64: at least 8 of them per workgroup
-    int splits = ((512 + tiles - 1) / tiles + 7) / 8 * 8;
+    int splits = ((want + tiles - 1) / tiles + 7) / 8 * 8;
     long max_splits = batch / (8 * BKH);
     if (max_splits < 1) max_splits = 1;
     if (splits > max_splits) splits = (int)max_splits;
@@ -391,12 +420,15 @@ int weight_gradient_bf16(const bf16_t* Err, int rows_out, int ld_err, const bf16
     wa.g.C = workspace; wa.g.ldc = cols; wa.g.M = rows_out; wa.g.N = cols; wa.g.K = (int)batch;
     wa.g.epilogue = EPI_SPLITK; wa.g.splits = pl.splits; wa.g.k_chunk = pl.k_chunk;
     wa.err = Err; wa.act = Act; wa.ld_err = ld_err; wa.ld_act = ld_act;
-    wa.tiles_m = (rows_out + 127) / 128;
-    wa.tiles_n = (cols + 127) / 128;
+    wa.tiles_m = (rows_out + pl.tile_n - 1) / pl.tile_n;
+    wa.tiles_n = (cols + pl.tile_n - 1) / pl.tile_n;
     const long grid = (long)wa.tiles_m * wa.tiles_n * pl.splits;
     {
         ProfScope prof(K_GEMM_WGRAD, 2.0 * rows_out * cols * (double)batch);
-        hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, stream(), wa);
+        if (pl.tile_n == 256)
+            hipLaunchKernelGGL((wgrad_bf16_kernel<2, 4, 4, 2>), dim3((unsigned)grid), dim3(512), 0, stream(), wa);
+        else
+            hipLaunchKernelGGL((wgrad_bf16_kernel<2, 2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, stream(), wa);
     }
     if (hipGetLastError() != hipSuccess) return NERF_ERR_HIP;
     const size_t n = (size_t)rows_out * cols;

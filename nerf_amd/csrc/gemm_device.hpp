@@ -63,11 +63,11 @@ __device__ __forceinline__ void decode_block(const KernelArgs& ka, int b, int& t
 // applied to the SOURCE address.  KC tiles are [ROWS][8 chunks of 16 B] with chunk c of row r
 // stored at position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 lane group touches then fall on
 // 16 different bank slots without padding.  KS tiles ([32][ROWS]) need no swizzle.
-template <bool KC, int ROWS>
+template <bool KC, int ROWS, int NT = 256>
 struct DmaLoader {
     static constexpr int SLOTS = ROWS * BK / 4;  // 16-byte pieces per tile
-    static constexpr int PASSES = SLOTS / 256;
-    static_assert(SLOTS % 256 == 0, "tile must split evenly over 256 lanes");
+    static constexpr int PASSES = SLOTS / NT;    // NT = threads of the workgroup
+    static_assert(SLOTS % NT == 0, "tile must split evenly over the workgroup's lanes");
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned voff[PASSES];
     unsigned tile_stride;
@@ -85,7 +85,7 @@ struct DmaLoader {
         }
 #pragma unroll
         for (int p = 0; p < PASSES; p++) {
-            const int L = p * 256 + tid;  // slot of the LDS image this lane fills in pass p
+            const int L = p * NT + tid;  // slot of the LDS image this lane fills in pass p
             if (KC) {
                 const int row = L >> 3, c = (L & 7) ^ ((row >> 1) & 7);
                 voff[p] = (unsigned)(row * ld + c * 4) * 4u;
@@ -104,7 +104,7 @@ struct DmaLoader {
 #pragma unroll
         for (int p = 0; p < PASSES; p++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void*)(tile + (p * 256 + wave * 64) * 4), 16, voff[p], soff, 0, 0);
+                rsrc, (__attribute__((address_space(3))) void*)(tile + (p * NT + wave * 64) * 4), 16, voff[p], soff, 0, 0);
     }
 };
 
@@ -116,10 +116,9 @@ struct DmaLoader {
 // per-element address arithmetic or branches.
 template <int MI, int NI>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[MI][NI], int m0, int n0, int split,
-                                         int wrow, int wcol, int lane) {
+                                         int wrow, int wcol, int lane, int tile_rows = 128) {
     float* C = p.C;
     if (p.epilogue == EPI_SPLITK) C += (size_t)split * p.M * p.ldc;
-    const int tile_rows = 128;
     const int rows_here = (p.M - m0) < tile_rows ? (p.M - m0) : tile_rows;
     const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 4u;
     // EPI_SWISH with C == nullptr (forward-only MLPs of the renderer: only the activation is wanted):

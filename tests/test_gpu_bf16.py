@@ -49,7 +49,9 @@ def test_convert_rounds_to_nearest_even_and_transposes(gpu):
     assert np.array_equal(gt[:, :37], to_bf16_bits(x).T) and not gt[:, 37:].any()
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 512, 192), (4096, 512, 512), (130, 1024, 1024), (77, 12, 128)])
+# the last three are large enough for the 256x256-tile kernel (>= 256 such tiles), ragged in M and N
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 512, 192), (4096, 512, 512), (130, 1024, 1024), (77, 12, 128),
+                                   (16500, 1024, 128), (32768, 512, 192), (33000, 520, 64)])
 @pytest.mark.parametrize("epilogue", [0, 1, 2])
 def test_nt_product(gpu, M, N, K, epilogue):
     from nerf_amd._lib import lib
