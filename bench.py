@@ -148,7 +148,7 @@ def render_workload(args, lib, torch):
         "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": el / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"forward-only render of one {W}x{H} view, {args.samples} samples/ray, chunks of "
-                               f"{args.rays} rays, MLP 150-512-512-512-4, fp32 (BASELINE config 2)"},
+                               f"{args.rays} rays, MLP 150-512-512-512-4, fp32"},
         "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<true, true, 2, 2, 2, 2> (forward products)",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
@@ -158,7 +158,7 @@ def render_workload(args, lib, torch):
 
 
 def bf16_workload(args, lib, torch):
-    """BASELINE config 5: a 1 048 576-ray batch x 256 samples per optimizer step, MLP 150-1024-512-1024-4,
+    """The reduced-precision configuration: a 1 048 576-ray batch x 256 samples per optimizer step, MLP 150-1024-512-1024-4,
     bf16 operands / fp32 accumulation, run as micro-batches of 8192 rays whose gradients add up in fp32."""
     import numpy as np
 
@@ -208,7 +208,7 @@ def bf16_workload(args, lib, torch):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 operands, f32 accumulate",
         "data": "synthetic",
         "config": {"workload": f"{rays_total} rays x {S} samples per optimizer step in {n_micro} micro-batches of "
-                               f"{micro} rays, MLP 150-{hidden}-{inter}-{hidden}-4 (BASELINE config 5)"},
+                               f"{micro} rays, MLP 150-{hidden}-{inter}-{hidden}-4"},
         "final_loss_per_ray": tr.last_loss() * micro / rays_total,
         "roofline": {"bound": "mfma", "kernel": f"bf16 products ({dom}: v_mfma_f32_32x32x16_bf16)", "achieved": achieved,
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
@@ -226,10 +226,10 @@ def main():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step")
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--workload", choices=["train", "render", "bf16"], default="train",
-                    help="train: the benchmark of record (BASELINE config 3).  render: forward-only render of one "
-                         "800x800 view at 128 samples/ray (BASELINE config 2), N = 1 only, reported separately.  "
+                    help="train: the benchmark of record.  render: forward-only render of one "
+                         "800x800 view at 128 samples/ray, N = 1 only, reported separately.  "
                          "bf16: 1M rays x 256 samples per step in micro-batches, hidden width 1024, bf16 operands "
-                         "with fp32 accumulation (BASELINE config 5), N = 1 only, reported separately")
+                         "with fp32 accumulation, N = 1 only, reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on device 0 with the gloo backend: exercises the multi-rank code path "
@@ -391,7 +391,7 @@ def main():
             "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {
                 "workload": "full training step (encode + fwd + composite + bwd + AdamW), "
-                            f"{R} rays x {S} samples per GPU, MLP 150-512-512-512-4, fp32 (BASELINE config 3)",
+                            f"{R} rays x {S} samples per GPU, MLP 150-512-512-512-4, fp32",
                 "rays_per_gpu": R,
                 "global_rays": R * world,
                 "samples_per_ray": S,

@@ -115,7 +115,7 @@ def test_render_test_image_writes_the_interpolated_view(gpu, oracle, libc, tmp_p
 
 
 def test_dataset_resolution_render_full_size(gpu, oracle_fast):
-    """BASELINE config 2 at full size: one 800x800 view, 128 samples/ray, 150-512-512-512-4.
+    """The dataset-resolution render at full size: one 800x800 view, 128 samples/ray, 150-512-512-512-4.
     Size-independent properties (chunking is invisible; repeated renders are bit-identical) plus
     the oracle on a scattered handful of the 640 000 pixels."""
     from oracle.pyoracle import ACC_F64

@@ -207,7 +207,7 @@ def test_create_rejects_bad_config(gpu):
 
 
 def test_full_size_step_properties(gpu, oracle_fast):
-    """BASELINE config 3 at full size (4096 rays x 128 samples, 150-512-512-512-4), where the
+    """The benchmark configuration at full size (4096 rays x 128 samples, 150-512-512-512-4), where the
     oracle's whole step is too slow to run: additivity over ray shards, reproducibility, and the
     oracle on a scattered subset of rays (rays are independent in the forward pass)."""
     from oracle.pyoracle import ACC_F64
