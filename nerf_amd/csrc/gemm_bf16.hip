@@ -95,6 +95,51 @@ __device__ __forceinline__ void nt_tile(float (&lds)[2][(WM * MI + WN * NI) * 32
     __syncthreads();
 }
 
+// Epilogue of the k-contiguous products: lane owns point m = lane & 31 of each 32-point block and, per
+// register group q = r >> 2, the 4 consecutive features n = 8q + 4 (lane >> 5) + (0..3): 8 bytes of a bf16 row.
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&acc)[NI][MI], int m0, int n0, int wm, int wn,
+                                              int lane) {
+    constexpr int BM_ = WM * MI * 32;
+    const int rows_here = (p.M - m0) < BM_ ? (p.M - m0) : BM_;
+    const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 2u;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.C + (size_t)m0 * p.ldc), 0, p.C ? panel_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.epilogue == EPI_SWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((p.epilogue == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+        const int m_local = (wm * MI + mi) * 32 + (lane & 31);
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            const int n_first = n0 + (wn * NI + ni) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int n = n_first + 8 * q;
+                const unsigned voff = (n + 3 < p.N) ? (unsigned)(m_local * p.ldc + n) * 2u : OOR;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[ni][mi][4 * q + e];
+                if (p.epilogue == EPI_DSWISH_MUL) {
+                    const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rAUX, voff, 0, 0));
+                    v[0] *= dswish_f(bf16_lo(a[0])); v[1] *= dswish_f(bf16_hi(a[0]));
+                    v[2] *= dswish_f(bf16_lo(a[1])); v[3] *= dswish_f(bf16_hi(a[1]));
+                }
+                u32x2 out = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(out, rC, voff, 0, 0);
+                if (p.epilogue == EPI_SWISH) {
+                    // the activation of the ROUNDED pre-activation: what the backward pass will recompute from
+                    const u32x2 act = {pack_bf16(swish_f(bf16_lo(out[0])), swish_f(bf16_hi(out[0]))),
+                                       pack_bf16(swish_f(bf16_lo(out[1])), swish_f(bf16_hi(out[1])))};
+                    __builtin_amdgcn_raw_buffer_store_b64(act, rC2, voff, 0, 0);
+                }
+            }
+        }
+    }
+}
+
 template <int WM, int WN, int MI, int NI>
 __global__ __launch_bounds__(WM * WN * 64, 512 / (WM * WN * 64)) void gemm_bf16_nt_kernel(const NtArgs ka) {
     constexpr int NTH = WM * WN * 64, BM_ = WM * MI * 32, BN_ = WN * NI * 32;
@@ -142,45 +187,7 @@ __global__ __launch_bounds__(WM * WN * 64, 512 / (WM * WN * 64)) void gemm_bf16_
     }
     if (kt < nkt) nt_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, wm, wn, lane);
 
-    // ---- epilogue: lane owns point m = lane & 31 of each 32-point block and, per register group
-    // q = r >> 2, the 4 consecutive features n = 8q + 4 (lane >> 5) + (0..3): 8 bytes of a bf16 row
-    const int rows_here = (p.M - m0) < BM_ ? (p.M - m0) : BM_;
-    const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 2u;
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.C + (size_t)m0 * p.ldc), 0, p.C ? panel_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((p.epilogue == EPI_SWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((p.epilogue == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
-#pragma unroll
-    for (int mi = 0; mi < MI; mi++) {
-        const int m_local = (wm * MI + mi) * 32 + (lane & 31);
-#pragma unroll
-        for (int ni = 0; ni < NI; ni++) {
-            const int n_first = n0 + (wn * NI + ni) * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int n = n_first + 8 * q;
-                const unsigned voff = (n + 3 < p.N) ? (unsigned)(m_local * p.ldc + n) * 2u : OOR;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[ni][mi][4 * q + e];
-                if (p.epilogue == EPI_DSWISH_MUL) {
-                    const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rAUX, voff, 0, 0));
-                    v[0] *= dswish_f(bf16_lo(a[0])); v[1] *= dswish_f(bf16_hi(a[0]));
-                    v[2] *= dswish_f(bf16_lo(a[1])); v[3] *= dswish_f(bf16_hi(a[1]));
-                }
-                u32x2 out = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(out, rC, voff, 0, 0);
-                if (p.epilogue == EPI_SWISH) {
-                    // the activation of the ROUNDED pre-activation: what the backward pass will recompute from
-                    const u32x2 act = {pack_bf16(swish_f(bf16_lo(out[0])), swish_f(bf16_hi(out[0]))),
-                                       pack_bf16(swish_f(bf16_lo(out[1])), swish_f(bf16_hi(out[1])))};
-                    __builtin_amdgcn_raw_buffer_store_b64(act, rC2, voff, 0, 0);
-                }
-            }
-        }
-    }
+    nt_store_tile<WM, WN, MI, NI>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ================================================================================================
