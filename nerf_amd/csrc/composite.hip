@@ -52,6 +52,23 @@ __device__ __forceinline__ float wave_exclusive_product(float x, int lane) {
     return lane == 0 ? 1.0f : ex;
 }
 
+// Transmittance in front of this lane's first sample, multiplied up in the REFERENCE's order: one
+// running product over all samples, left to right (nerf.c:42, nerf.c:85).  Every lane walks the same
+// chain (the factors come by wave-uniform lane reads), so the value each lane keeps is bit for bit
+// what a sequential loop holds at that sample -- and with it the early-stop decision (nerf.c:43) is
+// the sequential loop's, not that of a differently associated scan.  S multiplies per ray: nothing
+// beside the 16 bytes per sample these kernels move.
+template <int SPL>
+__device__ __forceinline__ float sequential_transmittance(const float (&alpha)[SPL], int lane) {
+    float T = 1.0f, mine = 1.0f;
+    for (int l = 0; l < 64; l++) {
+        if (lane == l) mine = T;
+#pragma unroll
+        for (int i = 0; i < SPL; i++) T *= (1.0f - __shfl(alpha[i], l, 64));
+    }
+    return mine;
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
@@ -140,7 +157,7 @@ __global__ __launch_bounds__(256) void composite_forward_kernel(
         }
         local *= (1.0f - alpha[i]);
     }
-    float T = wave_exclusive_product(local, lane);
+    float T = SPACING ? wave_exclusive_product(local, lane) : sequential_transmittance<SPL>(alpha, lane);
     float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
     // transmittance in front of each sample, no early stop (nerf.c:82-86)
     float Tbefore[SPL];
     {
-        float T = wave_exclusive_product(local, lane);
+        float T = SPACING ? wave_exclusive_product(local, lane) : sequential_transmittance<SPL>(alpha, lane);
 #pragma unroll
         for (int i = 0; i < SPL; i++) {
             Tbefore[i] = T;

@@ -97,6 +97,7 @@ Image* load_png(const char* filename) {
     size_t idat_len = 0;
     Image* img = NULL;
     unsigned char* raw = NULL;
+    if (!idat) { free(buf); return NULL; }
 
     size_t pos = 8;
     while (pos + 12 <= (size_t)fsize) {
@@ -154,6 +155,9 @@ Image* load_png(const char* filename) {
         const size_t stride = (bits + 7) / 8;
         const int bpp = (channels * depth + 7) / 8;
         const size_t raw_len = (size_t)height * (stride + 1);
+        /* deflate expands by at most ~1032x: a header that promises more pixels than the
+         * compressed data can hold is damaged, and must not size an allocation */
+        if (raw_len / 1032 > idat_len + 64) goto fail;
         raw = (unsigned char*)malloc(raw_len);
         if (!raw) goto fail;
         uLongf out_len = (uLongf)raw_len;
@@ -161,10 +165,12 @@ Image* load_png(const char* filename) {
         if (png_unfilter(raw, height, stride, bpp < 1 ? 1 : bpp) != 0) goto fail;
 
         img = (Image*)malloc(sizeof(Image));
+        unsigned char* pixels = (unsigned char*)malloc((size_t)width * height * 4);
+        if (!img || !pixels) { free(img); free(pixels); img = NULL; goto fail; }
         img->width = width;
         img->height = height;
         img->channels = 4; /* always RGBA, as data.c:43 */
-        img->data = (unsigned char*)malloc((size_t)width * height * 4);
+        img->data = pixels;
         const unsigned maxv = depth == 16 ? 0xFFFFu : ((1u << depth) - 1u);
         for (int y = 0; y < height; y++) {
             const unsigned char* line = raw + (size_t)y * (stride + 1) + 1;

@@ -100,6 +100,77 @@ def test_early_stop_is_reproduced(gpu, oracle):
     assert np.all(g[1, :, 0] == 0)            # ReLU derivative at density 0 (nerf.c:123)
 
 
+def _alpha32(dens):
+    """alpha of nerf.c:35 in float32 with a correctly rounded exp (what the device computes)"""
+    x = -(dens.astype(np.float32) * np.float32(0.01))
+    return np.float32(1) - np.exp(x.astype(np.float64)).astype(np.float32)
+
+
+def _sequential_pixels(dens, rgb):
+    """nerf.c:29-44 sample after sample in float32: dens [R,S], rgb [R,S,3] -> pixels, stop index"""
+    R, S = dens.shape
+    alpha = _alpha32(dens)
+    T = np.ones(R, np.float32)
+    live = np.ones(R, bool)
+    pix = np.zeros((R, 3), np.float32)
+    stop = np.full(R, S, np.int64)
+    for s in range(S):
+        w = alpha[:, s] * T
+        pix += np.where(live[:, None], w[:, None] * rgb[:, s], np.float32(0))
+        T = np.where(live, T * (np.float32(1) - alpha[:, s]), T)
+        hit = live & (T < np.float32(0.01))
+        stop[hit] = s
+        live &= ~hit
+    return pix, stop
+
+
+def test_stop_decision_is_the_sequential_loops(gpu):
+    """Rays built to sit ON the early-stop boundary: the density of sample k is the largest float for
+    which the running product (multiplied up left to right in float32, nerf.c:42) is still >= 0.01,
+    or the next float after it.  The samples behind k are opaque and white, so a stop taken one
+    sample early or late moves the pixel by ~5e-3.  The device has to take the sequential loop's
+    decision on every such ray -- a product associated any other way flips some of them."""
+    from nerf_amd.api import DeviceArray
+    from nerf_amd._lib import lib
+    rng = np.random.default_rng(4242)
+    R, S = 512, 128
+    dens = np.zeros((R, S), np.float32)
+    k = rng.integers(20, 100, size=R)
+    for r in range(R):
+        # transmittance 0.02 .. 0.05 in front of sample k, spread unevenly over the earlier samples
+        share = rng.random(k[r]) + 0.05
+        dens[r, :k[r]] = (-np.log(rng.uniform(0.02, 0.05)) * share / share.sum() / 0.01).astype(np.float32)
+        Tk = np.float32(1)
+        for a in _alpha32(dens[r, :k[r]]):
+            Tk = np.float32(Tk * (np.float32(1) - a))
+        assert Tk >= np.float32(0.01)
+        lo, hi = np.float32(0).view(np.int32), np.float32(1000).view(np.int32)   # positive floats order like their bits
+        below = lambda bits: np.float32(Tk * (np.float32(1) - _alpha32(np.array([bits], np.int32).view(np.float32))[0])) < np.float32(0.01)
+        assert not below(lo) and below(hi)
+        while hi - lo > 1:
+            mid = (int(lo) + int(hi)) // 2
+            if below(np.int32(mid)):
+                hi = np.int32(mid)
+            else:
+                lo = np.int32(mid)
+        dens[r, k[r]] = np.array([hi if r & 1 else lo], np.int32).view(np.float32)[0]
+        dens[r, k[r] + 1:] = 100.0
+    rgb = rng.random((R, S, 3)).astype(np.float32)
+    for r in range(R):
+        rgb[r, k[r] + 1:] = 1.0
+    want, stop = _sequential_pixels(dens, rgb)
+    assert np.array_equal(stop == k, (np.arange(R) & 1) == 1)       # odd rays stop at k, even rays go on
+    assert (stop[::2] > k[::2]).all()
+
+    d_dens, d_rgb = DeviceArray.from_numpy(dens.reshape(-1)), DeviceArray.from_numpy(rgb.reshape(-1, 3))
+    d_t = DeviceArray.zeros((R * S, 3))
+    d_pix, d_err, d_loss = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray.zeros((1,))
+    lib.volume_rendering_and_loss_launch(d_dens.ptr, d_rgb.ptr, d_t.ptr, d_pix.ptr, d_err.ptr, d_loss.ptr, R, S)
+    pix = d_pix.numpy()
+    wrong = np.abs(pix - want).max(axis=1) > PIX_ATOL
+    assert not wrong.any(), f"{wrong.sum()} of {R} boundary rays took the other stop decision"
+
+
 @pytest.mark.parametrize("R,S", [(16, 128), (6, 256), (5, 77)])
 def test_fused_raw_forms_match_launchers(gpu, R, S):
     """nerf_composite_forward/backward on the raw MLP output = activation + the two launchers."""
