@@ -54,6 +54,18 @@ float nerf_event_elapsed_ms(void* start, void* stop);
  * C2 = swish(C); 2: C = product .* swish'(AUX), AUX shaped like C. */
 int nerf_gemm_f32(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc, int M,
                   int N, int K, int epilogue, float* C2, const float* AUX);
+/* The same product in split-bf16 arithmetic: each fp32 operand value is split into a bf16 head and a
+ * bf16 remainder and a*b is formed from three bf16 matrix-core products with fp32 accumulation
+ * (about 16 significant bits per operand; relative error per product <= ~1.1e-5).  No counterpart in
+ * the reference, whose BLAS mode (train.c:86) is coarser still.  Needs 16-byte aligned operands with
+ * leading dimensions that are multiples of 4 and K a multiple of 32; returns 1 otherwise. */
+int nerf_gemm_split_bf16(const float* A, int lda, int a_kc, const float* B, int ldb, int b_kc, float* C, int ldc,
+                         int M, int N, int K, int epilogue, float* C2, const float* AUX);
+/* nerf_weight_gradient in split-bf16 arithmetic (its own slab plan, hence its own workspace size).
+ * Needs rows_out, ld_act multiples of 4 and 16-byte aligned operands; returns 1 otherwise. */
+size_t nerf_weight_gradient_split_workspace(int rows_out, int cols, long batch);
+int nerf_weight_gradient_split(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act, long batch,
+                               float* d_dW, float* d_workspace, size_t workspace_bytes, int accumulate);
 /* dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]: split over the batch into slabs
  * in d_workspace (nerf_weight_gradient_workspace bytes), then summed in a fixed order.  Rows of Act
  * are ld_act >= cols floats apart. */
@@ -150,14 +162,19 @@ typedef struct {
     int pos_enc_l, dir_enc_l;                   /* train.c:20-21 */
     int hidden_dim, intermediate_dim, output_dim; /* train.c:42-44 */
     float learning_rate;                        /* train.c:160 */
-    int precision;                              /* NERF_PRECISION_F32 (the reference's arithmetic) or _BF16 */
+    int precision;                              /* NERF_PRECISION_F32 (the reference's arithmetic), _BF16 or _SPLIT_BF16 */
     int quadrature;                             /* NERF_QUADRATURE_REFERENCE or _SPACING (see nerf_composite_*_spacing) */
 } NerfTrainerConfig;
 enum { NERF_QUADRATURE_REFERENCE = 0, NERF_QUADRATURE_SPACING = 1 };
 /* NERF_PRECISION_BF16: activations and the weights as the matrix cores read them are bf16, products
  * accumulate in fp32, master weights / gradients / AdamW / compositing stay fp32.  Needs hidden and
  * intermediate widths that are multiples of 64.  No counterpart in the reference. */
-enum { NERF_PRECISION_F32 = 0, NERF_PRECISION_BF16 = 1 };
+enum { NERF_PRECISION_F32 = 0, NERF_PRECISION_BF16 = 1, NERF_PRECISION_SPLIT_BF16 = 2 };
+/* NERF_PRECISION_SPLIT_BF16: everything is stored and handled as in NERF_PRECISION_F32; only the
+ * products inside the MLP's large matrix multiplications are formed in split-bf16 arithmetic (see
+ * nerf_gemm_split_bf16: three bf16 matrix-core products per fp32 product, ~16 significant bits per
+ * operand, fp32 accumulation).  Results stay within the fp32 parity tolerance (1e-4 of the largest
+ * entry); the step runs about twice as fast.  No counterpart in the reference. */
 
 void nerf_trainer_default_config(NerfTrainerConfig* cfg);
 /* number of weights of the two MLPs: hidden*pe + intermediate*hidden + hidden*intermediate + output*hidden */

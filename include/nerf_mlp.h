@@ -60,6 +60,7 @@ typedef struct {
     float* d_workspace;     /* split-K partial slabs for the weight-gradient products */
     size_t workspace_bytes;
     int owns_params;        /* 0 when weights/gradients/moments live in a caller-provided arena */
+    int matrix_math;        /* 0: exact fp32 products (default); 1: split-bf16 (nerf_mlp_set_matrix_math) */
 } MLP;
 
 MLP* init_mlp(int input_dim, int hidden_dim, int output_dim, int batch_size, void* handle);
@@ -70,6 +71,10 @@ void forward_pass_mlp(MLP* mlp, float* d_X);
 void zero_gradients_mlp(MLP* mlp);
 void backward_pass_mlp(MLP* mlp, float* d_X, float* d_grad_X);
 void update_weights_mlp(MLP* mlp, float learning_rate);
+/* No counterpart in the reference: chooses how the MLP's large matrix products form a*b.
+ * 0 (default): exact fp32; 1: split-bf16 (three bf16 matrix-core products, fp32 accumulation; see
+ * nerf_gemm_split_bf16 in nerf_amd.h).  Returns 0, or 1 for a bad argument. */
+int nerf_mlp_set_matrix_math(MLP* mlp, int math);
 
 /* The reference's error macros (used at train.c:48,85,148-154,...) spelled for HIP. */
 #define CHECK_HIP(call)                                                                                  \

@@ -57,6 +57,7 @@ class MLP(C.Structure):  # include/nerf_mlp.h
         ("input_dim", C.c_int), ("hidden_dim", C.c_int), ("output_dim", C.c_int), ("batch_size", C.c_int),
         ("handle", C.c_void_p),
         ("d_workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("owns_params", C.c_int),
+        ("matrix_math", C.c_int),
     ]
 
 
@@ -99,6 +100,11 @@ _SIGS = {
     # matrix products
     "nerf_gemm_f32": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, VP, VP]),
+    "nerf_gemm_split_bf16": (C.c_int, [VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, VP, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, VP, VP]),
+    "nerf_weight_gradient_split_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_long]),
+    "nerf_weight_gradient_split": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_long, VP, VP, C.c_size_t, C.c_int]),
+    "nerf_mlp_set_matrix_math": (C.c_int, [VP, C.c_int]),
     "nerf_weight_gradient_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_long]),
     "nerf_weight_gradient": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_long, VP, VP, C.c_size_t, C.c_int]),
     "nerf_convert_bf16": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_int]),

@@ -73,11 +73,22 @@ struct GemmArgs {
     int epilogue;
     int splits;       // EPI_SPLITK: number of contraction chunks (C = slabs base, chunk s at C + s*M*ldc)
     int k_chunk;      // EPI_SPLITK: contraction rows per chunk (multiple of 32)
-    int tile_n;       // EPI_SPLITK: output tile width the caller planned with (128 or 160)
+    int tile_n;       // EPI_SPLITK: output tile width the caller planned with (128, 160; 256: split-bf16 only)
+};
+
+// How a matrix product forms a*b from its fp32 operands.
+enum MatrixMath {
+    MATH_EXACT = 0,       // fp32 MFMA: a k-ordered chain of fp32 fused multiply-adds
+    MATH_SPLIT_BF16 = 1,  // hi/lo bf16 split of both operands, three bf16 MFMA products, fp32 accumulation
 };
 
 // Enqueues the product; returns NERF_OK or NERF_ERR_ARG (unsupported shape/alignment).
 int gemm_f32(const GemmArgs& args);
+
+// The same product in split-bf16 arithmetic (gemm_split.hip).  Needs 16-byte aligned operands and K a
+// multiple of 32 (gemm_split_supported); callers fall back to gemm_f32 otherwise.
+int gemm_split(const GemmArgs& args);
+bool gemm_split_supported(const GemmArgs& args);
 
 // dst[i] = (accumulate ? dst[i] : 0) + sum_{s<splits} slabs[s*stride + i]   (fixed order: reproducible)
 void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate);
@@ -89,6 +100,7 @@ int wgrad_tile_n(int cols);
 // Plan of dW[rows_out][cols] += Err^T Act over `batch` points: splits, rows per split, tile width.
 struct WgradPlan { int splits, k_chunk, tile_n; };
 WgradPlan plan_weight_gradient(int rows_out, int cols, long batch);
+WgradPlan plan_weight_gradient_split(int rows_out, int cols, long batch);  // for gemm_split's tile shapes
 
 // ---- bf16 matrix products (bf16 operands in memory, fp32 accumulation) --------------------------
 typedef unsigned short bf16_t;  // storage type of a bf16 value

@@ -107,7 +107,21 @@ struct DmaLoader {
                 rsrc, (__attribute__((address_space(3))) void*)(tile + (p * NT + wave * 64) * 4), 16, voff[p], soff, 0, 0);
     }
 };
-
+// One 8-step group of an operand tile staged by DmaLoader, as the 32x32 MFMAs want it:
+// frag[j]: lane l holds element (row rb + (l & 31), k = 8kk + 4(l >> 5) + j)
+template <bool KC, int ROWS>
+__device__ __forceinline__ void dma_frag(float (&frag)[4], const float* __restrict__ T, int rb, int kk, int lane) {
+    if (KC) {
+        const int row = rb + (lane & 31);
+        const int chunk = (kk * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * BK + chunk * 4);
+        frag[0] = v[0]; frag[1] = v[1]; frag[2] = v[2]; frag[3] = v[3];
+    } else {
+        const float* src = T + (kk * 8 + 4 * (lane >> 5)) * ROWS + rb + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 4; j++) frag[j] = src[j * ROWS];
+    }
+}
 
 // ---- epilogue -------------------------------------------------------------------------------------
 // Accumulator register r of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).

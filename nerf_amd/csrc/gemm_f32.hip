@@ -41,21 +41,6 @@ constexpr int KC_LD = BK + 4;  // generic kernel: floats per LDS row of a KC til
 // ================================================================================================
 // Fast path: LDS-DMA operand staging (DmaLoader: gemm_device.hpp)
 // ================================================================================================
-// frag[j] feeds MFMA j of the 8-step group kk: lane l holds element (row rb + (l & 31), k = 8kk + 4(l >> 5) + j)
-template <bool KC, int ROWS>
-__device__ __forceinline__ void dma_frag(float (&frag)[4], const float* __restrict__ T, int rb, int kk, int lane) {
-    if (KC) {
-        const int row = rb + (lane & 31);
-        const int chunk = (kk * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * BK + chunk * 4);
-        frag[0] = v[0]; frag[1] = v[1]; frag[2] = v[2]; frag[3] = v[3];
-    } else {
-        const float* src = T + (kk * 8 + 4 * (lane >> 5)) * ROWS + rb + (lane & 31);
-#pragma unroll
-        for (int j = 0; j < 4; j++) frag[j] = src[j * ROWS];
-    }
-}
-
 // One K-tile: start the DMA of tile `next` into the other buffer, run the 32 contraction steps of
 // buffer CUR, barrier.  (`next` past the end re-fetches the last tile; it is never read.)
 template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int CUR>

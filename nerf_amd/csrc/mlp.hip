@@ -231,31 +231,46 @@ WgradPlan plan_weight_gradient(int rows_out, int cols, long batch) {
     return pl;
 }
 
+// slab bytes of a weight-gradient product under either arithmetic (the MLP may be switched later)
+static size_t wgrad_slab_bytes(int rows_out, int cols, long batch) {
+    const int a = plan_weight_gradient(rows_out, cols, batch).splits;
+    const int b = plan_weight_gradient_split(rows_out, cols, batch).splits;
+    return (size_t)(a > b ? a : b) * rows_out * cols * sizeof(float);
+}
+
 size_t mlp_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int batch_size) {
-    const size_t need = (size_t)plan_weight_gradient(hidden_dim, input_dim, batch_size).splits * hidden_dim *
-                        input_dim * sizeof(float);
+    const size_t need = wgrad_slab_bytes(hidden_dim, input_dim, batch_size);
     const size_t need2 = skinny_ok(hidden_dim, output_dim)
                              ? skinny_backward_workspace(batch_size, hidden_dim, output_dim)
-                             : (size_t)plan_weight_gradient(output_dim, hidden_dim, batch_size).splits * output_dim *
-                                   hidden_dim * sizeof(float);
+                             : wgrad_slab_bytes(output_dim, hidden_dim, batch_size);
     return need > need2 ? need : need2;
+}
+
+// the product under the arithmetic `math` asks for; shapes the split-bf16 kernels do not take
+// (ragged or unaligned operands) run on the exact kernels
+static int run_gemm(const GemmArgs& g, int math) {
+    if (math == MATH_SPLIT_BF16 && gemm_split_supported(g)) return gemm_split(g);
+    return gemm_f32(g);
 }
 
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T * Act[batch][cols]
 // Act rows are ld_act floats apart (ld_act >= cols; the trainer pads the 150-wide encoding to 160).
 void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, int ld_act, long batch, float* dW,
-                     float* workspace, int accumulate) {
-    const WgradPlan pl = plan_weight_gradient(rows_out, cols, batch);
-    const int splits = pl.splits;
+                     float* workspace, int accumulate, int math) {
     GemmArgs g = {};
     g.A = Err; g.lda = rows_out; g.a_kc = 0;
     g.B = Act; g.ldb = ld_act; g.b_kc = 0;
     g.C = workspace; g.ldc = cols;
     g.M = rows_out; g.N = cols; g.K = (int)batch;
-    g.epilogue = EPI_SPLITK; g.splits = splits; g.k_chunk = pl.k_chunk; g.tile_n = pl.tile_n;
+    g.epilogue = EPI_SPLITK;
+    const bool split_math = math == MATH_SPLIT_BF16 && gemm_split_supported(g);
+    const WgradPlan pl = split_math ? plan_weight_gradient_split(rows_out, cols, batch)
+                                    : plan_weight_gradient(rows_out, cols, batch);
+    const int splits = pl.splits;
+    g.splits = splits; g.k_chunk = pl.k_chunk; g.tile_n = pl.tile_n;
     {
         ProfScope prof(K_GEMM_WGRAD, 2.0 * rows_out * cols * (double)batch);
-        if (gemm_f32(g) != NERF_OK) {
+        if ((split_math ? gemm_split(g) : gemm_f32(g)) != NERF_OK) {
             fprintf(stderr, "weight_gradient: product [%d x %d] over %ld rows failed\n", rows_out, cols, batch);
             exit(EXIT_FAILURE);
         }
@@ -280,7 +295,7 @@ void mlp_forward(MLP* mlp, const PitchedInput& in) {
     g.epilogue = EPI_SWISH;
     {
         ProfScope prof(K_GEMM_FWD, 2.0 * (double)B * mlp->hidden_dim * mlp->input_dim);
-        if (gemm_f32(g) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 1 failed\n"); exit(EXIT_FAILURE); }
+        if (run_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 1 failed\n"); exit(EXIT_FAILURE); }
     }
     if (skinny_ok(mlp->hidden_dim, mlp->output_dim)) {
         skinny_forward(mlp->d_layer_postact, mlp->d_W2, mlp->d_layer_output, B, mlp->hidden_dim, mlp->output_dim);
@@ -292,7 +307,7 @@ void mlp_forward(MLP* mlp, const PitchedInput& in) {
         h.M = (int)B; h.N = mlp->output_dim; h.K = mlp->hidden_dim;
         h.epilogue = EPI_STORE;
         ProfScope prof(K_GEMM_FWD, 2.0 * (double)B * mlp->hidden_dim * mlp->output_dim);
-        if (gemm_f32(h) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 2 failed\n"); exit(EXIT_FAILURE); }
+        if (run_gemm(h, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 2 failed\n"); exit(EXIT_FAILURE); }
     }
 }
 
@@ -306,7 +321,7 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
                         hid, out, mlp->d_workspace, accumulate);
     } else {
         weight_gradient(mlp->d_error_output, out, mlp->d_layer_postact, hid, hid, B, mlp->d_W2_grad,
-                        mlp->d_workspace, accumulate);
+                        mlp->d_workspace, accumulate, mlp->matrix_math);
         GemmArgs g = {};
         g.A = mlp->d_error_output; g.lda = out; g.a_kc = 1;
         g.B = mlp->d_W2; g.ldb = hid; g.b_kc = 0;
@@ -314,9 +329,10 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
         g.M = (int)B; g.N = hid; g.K = out;
         g.epilogue = EPI_DSWISH_MUL;
         ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * out);
-        if (gemm_f32(g) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: hidden error failed\n"); exit(EXIT_FAILURE); }
+        if (run_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: hidden error failed\n"); exit(EXIT_FAILURE); }
     }
-    weight_gradient(mlp->d_error_hidden, hid, d_X, in, ld_X, B, mlp->d_W1_grad, mlp->d_workspace, accumulate);
+    weight_gradient(mlp->d_error_hidden, hid, d_X, in, ld_X, B, mlp->d_W1_grad, mlp->d_workspace, accumulate,
+                    mlp->matrix_math);
     if (d_grad_X) {
         GemmArgs g = {};
         g.A = mlp->d_error_hidden; g.lda = hid; g.a_kc = 1;
@@ -325,7 +341,7 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
         g.M = (int)B; g.N = in; g.K = hid;
         g.epilogue = EPI_STORE;
         ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * in);
-        if (gemm_f32(g) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: input gradient failed\n"); exit(EXIT_FAILURE); }
+        if (run_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: input gradient failed\n"); exit(EXIT_FAILURE); }
     }
 }
 
@@ -534,12 +550,37 @@ extern "C" size_t nerf_weight_gradient_workspace(int rows_out, int cols, long ba
     return (size_t)nerf::plan_weight_gradient(rows_out, cols, batch).splits * rows_out * cols * sizeof(float);
 }
 
+extern "C" size_t nerf_weight_gradient_split_workspace(int rows_out, int cols, long batch) {
+    return (size_t)nerf::plan_weight_gradient_split(rows_out, cols, batch).splits * rows_out * cols * sizeof(float);
+}
+
+extern "C" int nerf_weight_gradient_split(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act,
+                                          long batch, float* d_dW, float* d_workspace, size_t workspace_bytes,
+                                          int accumulate) {
+    if (!d_err || !d_act || !d_dW || !d_workspace || rows_out <= 0 || cols <= 0 || batch <= 0 || ld_act < cols)
+        return NERF_ERR_ARG;
+    nerf::GemmArgs probe = {};
+    probe.A = d_err; probe.lda = rows_out; probe.B = d_act; probe.ldb = ld_act;
+    probe.M = rows_out; probe.N = cols; probe.K = (int)batch;
+    if (!nerf::gemm_split_supported(probe)) return NERF_ERR_ARG;
+    if (workspace_bytes < nerf_weight_gradient_split_workspace(rows_out, cols, batch)) return NERF_ERR_ARG;
+    nerf::weight_gradient(d_err, rows_out, d_act, cols, ld_act, batch, d_dW, d_workspace, accumulate,
+                          nerf::MATH_SPLIT_BF16);
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+extern "C" int nerf_mlp_set_matrix_math(MLP* mlp, int math) {
+    if (!mlp || (math != nerf::MATH_EXACT && math != nerf::MATH_SPLIT_BF16)) return NERF_ERR_ARG;
+    mlp->matrix_math = math;
+    return NERF_OK;
+}
+
 extern "C" int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act,
                                     long batch, float* d_dW, float* d_workspace, size_t workspace_bytes,
                                     int accumulate) {
     if (!d_err || !d_act || !d_dW || !d_workspace || rows_out <= 0 || cols <= 0 || batch <= 0 || ld_act < cols)
         return NERF_ERR_ARG;
     if (workspace_bytes < nerf_weight_gradient_workspace(rows_out, cols, batch)) return NERF_ERR_ARG;
-    nerf::weight_gradient(d_err, rows_out, d_act, cols, ld_act, batch, d_dW, d_workspace, accumulate);
+    nerf::weight_gradient(d_err, rows_out, d_act, cols, ld_act, batch, d_dW, d_workspace, accumulate, nerf::MATH_EXACT);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }

@@ -175,7 +175,9 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
         cfg->output_dim != 4 || cfg->hidden_dim <= 0 || cfg->intermediate_dim <= 0)
         return nullptr;
     if ((long long)cfg->rays_per_batch * cfg->num_samples > 0x7fffffffLL) return nullptr;
-    if (cfg->precision != NERF_PRECISION_F32 && cfg->precision != NERF_PRECISION_BF16) return nullptr;
+    if (cfg->precision != NERF_PRECISION_F32 && cfg->precision != NERF_PRECISION_BF16 &&
+        cfg->precision != NERF_PRECISION_SPLIT_BF16)
+        return nullptr;
     if (cfg->quadrature != NERF_QUADRATURE_REFERENCE && cfg->quadrature != NERF_QUADRATURE_SPACING) return nullptr;
     const bool bf16 = cfg->precision == NERF_PRECISION_BF16;
     if (bf16 && !bf16_step_supported(NERF_PE_DIM3(cfg->pos_enc_l) + NERF_PE_DIM3(cfg->dir_enc_l), cfg->hidden_dim,
@@ -217,6 +219,8 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
         tr->mlp2 = mlp_create(M, H, O, N, nullptr, P + o[2], P + o[3], G + o[2], G + o[3], Mo + o[2], V + o[2],
                               Mo + o[3], V + o[3], buffers);
         ok = tr->mlp1 && tr->mlp2;
+        if (ok && cfg->precision == NERF_PRECISION_SPLIT_BF16)
+            tr->mlp1->matrix_math = tr->mlp2->matrix_math = MATH_SPLIT_BF16;
         if (ok && bf16) {
             tr->bf = bf16_step_create(tr->pe_dim, H, M, O, N);
             ok = tr->bf != nullptr;
@@ -431,6 +435,10 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
     MLP* r2 = mlp_create(mlp2->input_dim, mlp2->hidden_dim, mlp2->output_dim, N, nullptr, mlp2->d_W1, mlp2->d_W2,
                          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+    if (r1 && r2) {  // render with the arithmetic the MLPs train with
+        r1->matrix_math = mlp1->matrix_math;
+        r2->matrix_math = mlp2->matrix_math;
+    }
     const int pe_ld = ((pe_dim + 31) / 32) * 32;  // pitched like the trainer's encoding (zero row tails)
     float *d_pe = nullptr, *d_pixel = nullptr, *d_w1p = nullptr;
     unsigned char* d_rgb8 = nullptr;
