@@ -36,6 +36,11 @@ GEMM_KERNEL = {
     "gemm_dgrad": "gemm_dma_kernel<true, false, 2, 2, 2, 2>",
     "gemm_wgrad": "gemm_dma_kernel<false, false, 2, 2, 2, 2>",
 }
+SPLIT_KERNEL = {
+    "gemm_fwd": "gemm_split_kernel<true, true, 2, 4, 4, 2>",
+    "gemm_dgrad": "gemm_split_kernel<true, false, 2, 4, 4, 2>",
+    "gemm_wgrad": "gemm_split_kernel<false, false, 2, 4, 4, 2>",
+}
 
 
 def pmc_traffic(kernel):
@@ -47,12 +52,13 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not files:
         return None, None
-    try:
-        rec = json.load(open(files[-1])).get(kernel)
+    for path in reversed(files):  # latest round first; a summary only holds the kernels its command ran
+        try:
+            rec = json.load(open(path)).get(kernel)
+        except (OSError, ValueError):
+            continue
         if rec and "hbm_read_bytes" in rec and "hbm_write_bytes" in rec:
             return rec["hbm_read_bytes"] + rec["hbm_write_bytes"], rec.get("mfma_util")
-    except (OSError, ValueError):
-        pass
     return None, None
 
 
@@ -360,7 +366,7 @@ def main():
         achieved = dwork / (dms * 1e-3) / 1e12
         all_ms = sum(v[0] for v in gemm.values())
         all_work = sum(v[2] for v in gemm.values())
-        traffic, mfma_util = (None, None) if split else pmc_traffic(GEMM_KERNEL[dom])
+        traffic, mfma_util = pmc_traffic((SPLIT_KERNEL if split else GEMM_KERNEL)[dom])
         kernel_label = f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles, LDS-DMA staged)"
         peak = PEAK_F32_MFMA_TFLOPS
         if split:
@@ -368,7 +374,7 @@ def main():
             # against the bf16 matrix peak
             achieved *= 3.0
             peak = PEAK_BF16_MFMA_TFLOPS
-            kernel_label = (f"gemm_split_kernel ({dom}: 3 x v_mfma_f32_32x32x16_bf16 per product on hi/lo bf16 "
+            kernel_label = (f"{SPLIT_KERNEL[dom]} ({dom}: 3 x v_mfma_f32_32x32x16_bf16 per product on hi/lo bf16 "
                             "splits of the fp32 operands, 256x256x32 tiles, LDS-DMA staged; achieved = executed bf16 FLOP/s)")
         for name, entry in kernels.items():  # the streaming kernels against the HBM peak
             if "gbs" in entry:

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Profiles bench.py on the GPU box: one rocprofv3 --kernel-trace --stats run and three separate
+# --pmc passes (counters never share a run with other trace domains), then the per-kernel summary.
+#   tools/profile_bench.sh TAG [bench.py arguments...]        (from the repository root)
+# Leaves gpurun_out/prof_TAG/{stats,p1,p2,p3}/ and gpurun_out/prof_TAG/pmc_summary.json.
+set -e -o pipefail
+TAG=$1; shift
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline $*"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" $ARGS > "$OUT/stats.log" 2>&1
+echo "stats pass done"
+timeout -s KILL 120 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/p1" -o p1 -- python3 "$ROOT/bench.py" $ARGS > "$OUT/p1.log" 2>&1
+echo "pmc pass 1 done"
+timeout -s KILL 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/p2" -o p2 -- python3 "$ROOT/bench.py" $ARGS > "$OUT/p2.log" 2>&1
+echo "pmc pass 2 done"
+timeout -s KILL 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/p3" -o p3 -- python3 "$ROOT/bench.py" $ARGS > "$OUT/p3.log" 2>&1
+echo "pmc pass 3 done"
+cd "$ROOT"
+python3 tools/pmc_summary.py "$OUT/pmc_summary.json" mfma="$OUT/p1/p1" fetch="$OUT/p2/p2" write="$OUT/p3/p3" > "$OUT/pmc_summary.txt"
+tail -5 "$OUT/stats.log"
