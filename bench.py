@@ -242,6 +242,10 @@ def main():
                          "split-bf16: same fp32 storage and step, every product of the large matrix "
                          "multiplications formed from three bf16 matrix-core products with fp32 accumulation "
                          "(~16 significant bits per operand; inside the 1e-4 parity tolerance); reported separately")
+    ap.add_argument("--fuse-linear-pair", action="store_true",
+                    help="train workload only: collapse mlp1's output layer and mlp2's input layer (no activation "
+                         "between them) into one product per point, gradients of both derived from it; same "
+                         "parameters and results to fp32 rounding, 45 %% fewer FLOPs; reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on device 0 with the gloo backend: exercises the multi-rank code path "
@@ -290,7 +294,11 @@ def main():
     host = synthetic_dataset(num_images=100, width=800, height=800, seed=1234)  # same scene on every rank
     dds = host.upload()
     split = args.math == "split-bf16"
-    cfg = trainer_config(rays_per_batch=R, num_samples=S, precision=2 if split else 0)
+    fused = bool(args.fuse_linear_pair)
+    cfg = trainer_config(rays_per_batch=R, num_samples=S, precision=2 if split else 0, fuse_linear_pair=int(fused))
+    # FLOPs the step executes per point: 3 465 216 as the reference arranges its layers, 1 892 352 with
+    # the linear pair collapsed (forward 2 x 340 992, weight gradients the same, data gradients 2 x 264 192)
+    flop_per_point = 1892352.0 if fused else 3465216.0
     n_params = int(lib.nerf_trainer_param_count(ctypes.byref(cfg)))
     params = dp.arena_tensor(n_params, device)
     grads = dp.arena_tensor(n_params + 4, device)
@@ -392,7 +400,9 @@ def main():
             "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
                             "profiles/*_pmc_summary.json)",
             "mfma_busy_frac_pmc": mfma_util,
-            "step_flop_frac_of_peak": (3465216.0 * R * S) / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "step_flop_frac_of_peak": None if split else
+            (flop_per_point * R * S) / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "executed_flop_per_point": flop_per_point,
             "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12,
             "gemm_share_of_step": all_ms / (elapsed * 1e3),
             "kernels": kernels,
@@ -414,7 +424,8 @@ def main():
             "config": {
                 "workload": "full training step (encode + fwd + composite + bwd + AdamW), "
                             f"{R} rays x {S} samples per GPU, MLP 150-512-512-512-4, "
-                            + ("fp32 with split-bf16 matrix products" if split else "fp32"),
+                            + ("fp32 with split-bf16 matrix products" if split else "fp32")
+                            + (", linear pair fused (opt-in, not the benchmark of record)" if fused else ""),
                 "rays_per_gpu": R,
                 "global_rays": R * world,
                 "samples_per_ray": S,

@@ -68,6 +68,7 @@ class NerfTrainerConfig(C.Structure):  # include/nerf_amd.h
         ("pos_enc_l", C.c_int), ("dir_enc_l", C.c_int),
         ("hidden_dim", C.c_int), ("intermediate_dim", C.c_int), ("output_dim", C.c_int),
         ("learning_rate", C.c_float), ("precision", C.c_int), ("quadrature", C.c_int),
+        ("fuse_linear_pair", C.c_int),
     ]
 
 

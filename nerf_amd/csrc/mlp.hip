@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
     w[i] = __fsub_rn(__fmul_rn(w[i], decay), upd);
 }
 
-bool skinny_ok(int hidden, int out_dim) {
+bool skinny_ok_impl(int hidden, int out_dim) {
     if (out_dim < 1 || out_dim > 4) return false;
     if (hidden % 4 != 0 || hidden > 1024) return false;
     const int tpr = hidden / 4;
@@ -160,6 +160,8 @@ int skinny_backward_blocks(long rows, int hidden) {
 }
 
 }  // namespace
+
+bool skinny_ok(int hidden, int out_dim) { return skinny_ok_impl(hidden, out_dim); }
 
 void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim) {
     ProfScope prof(K_SKINNY_FWD, (double)rows * (hidden + out_dim) * 4.0);
@@ -232,7 +234,7 @@ WgradPlan plan_weight_gradient(int rows_out, int cols, long batch) {
 }
 
 // slab bytes of a weight-gradient product under either arithmetic (the MLP may be switched later)
-static size_t wgrad_slab_bytes(int rows_out, int cols, long batch) {
+size_t wgrad_slab_bytes(int rows_out, int cols, long batch) {
     const int a = plan_weight_gradient(rows_out, cols, batch).splits;
     const int b = plan_weight_gradient_split(rows_out, cols, batch).splits;
     return (size_t)(a > b ? a : b) * rows_out * cols * sizeof(float);
@@ -248,7 +250,7 @@ size_t mlp_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int ba
 
 // the product under the arithmetic `math` asks for; shapes the split-bf16 kernels do not take
 // (ragged or unaligned operands) run on the exact kernels
-static int run_gemm(const GemmArgs& g, int math) {
+int mlp_gemm(const GemmArgs& g, int math) {
     if (math == MATH_SPLIT_BF16 && gemm_split_supported(g)) return gemm_split(g);
     return gemm_f32(g);
 }
@@ -295,7 +297,7 @@ void mlp_forward(MLP* mlp, const PitchedInput& in) {
     g.epilogue = EPI_SWISH;
     {
         ProfScope prof(K_GEMM_FWD, 2.0 * (double)B * mlp->hidden_dim * mlp->input_dim);
-        if (run_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 1 failed\n"); exit(EXIT_FAILURE); }
+        if (mlp_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 1 failed\n"); exit(EXIT_FAILURE); }
     }
     if (skinny_ok(mlp->hidden_dim, mlp->output_dim)) {
         skinny_forward(mlp->d_layer_postact, mlp->d_W2, mlp->d_layer_output, B, mlp->hidden_dim, mlp->output_dim);
@@ -307,7 +309,7 @@ void mlp_forward(MLP* mlp, const PitchedInput& in) {
         h.M = (int)B; h.N = mlp->output_dim; h.K = mlp->hidden_dim;
         h.epilogue = EPI_STORE;
         ProfScope prof(K_GEMM_FWD, 2.0 * (double)B * mlp->hidden_dim * mlp->output_dim);
-        if (run_gemm(h, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 2 failed\n"); exit(EXIT_FAILURE); }
+        if (mlp_gemm(h, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 2 failed\n"); exit(EXIT_FAILURE); }
     }
 }
 
@@ -329,7 +331,7 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
         g.M = (int)B; g.N = hid; g.K = out;
         g.epilogue = EPI_DSWISH_MUL;
         ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * out);
-        if (run_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: hidden error failed\n"); exit(EXIT_FAILURE); }
+        if (mlp_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: hidden error failed\n"); exit(EXIT_FAILURE); }
     }
     weight_gradient(mlp->d_error_hidden, hid, d_X, in, ld_X, B, mlp->d_W1_grad, mlp->d_workspace, accumulate,
                     mlp->matrix_math);
@@ -341,7 +343,7 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
         g.M = (int)B; g.N = in; g.K = hid;
         g.epilogue = EPI_STORE;
         ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * in);
-        if (run_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: input gradient failed\n"); exit(EXIT_FAILURE); }
+        if (mlp_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: input gradient failed\n"); exit(EXIT_FAILURE); }
     }
 }
 

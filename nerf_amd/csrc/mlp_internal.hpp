@@ -25,4 +25,14 @@ void mlp_forward(MLP* mlp, const PitchedInput& in);
 // accumulate = 1: add to the gradient buffers; 0: overwrite them.  ld_X = floats between rows of d_X.
 void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int accumulate);
 
+// Pieces of the two functions above, for callers that arrange the layers themselves (the trainer's
+// fused linear pair).  `math`: MATH_EXACT or MATH_SPLIT_BF16 (shapes the split kernels do not take
+// run exact).
+int mlp_gemm(const GemmArgs& g, int math);
+bool skinny_ok(int hidden, int out_dim);
+// dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]; workspace >= wgrad_slab_bytes(...)
+void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, int ld_act, long batch, float* dW,
+                     float* workspace, int accumulate, int math);
+size_t wgrad_slab_bytes(int rows_out, int cols, long batch);
+
 }  // namespace nerf

@@ -63,7 +63,7 @@ ProfScope::~ProfScope() {
 
 extern "C" {
 
-int nerf_amd_abi_version(void) { return 2; }
+int nerf_amd_abi_version(void) { return 3; }
 
 int nerf_set_device(int device) { return hipSetDevice(device) == hipSuccess ? NERF_OK : NERF_ERR_HIP; }
 

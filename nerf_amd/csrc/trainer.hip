@@ -48,6 +48,12 @@ struct NerfTrainer {
     int steps;
     const float* d_offsets_last;  // the sample offsets of the step in flight (spacing quadrature reads them again)
     Bf16Step* bf;     // non-null in the bf16-operand configuration (then d_pe, d_w1p and the MLPs' activations are absent)
+    // fuse_linear_pair: Wc = mlp2.W1 * mlp1.W2 [H][H], its gradient, a scratch matrix for the two
+    // derived gradients, and the slab workspace of the dWc product
+    float* d_wc;
+    float* d_dwc;
+    float* d_pair_tmp;
+    float* d_pair_ws;
 };
 
 namespace {
@@ -134,8 +140,89 @@ int after_forward_bf16(NerfTrainer* tr, int accumulate) {
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
+void must(int rc, const char* what) {
+    if (rc != NERF_OK) {
+        fprintf(stderr, "nerf_trainer: %s failed\n", what);
+        exit(EXIT_FAILURE);
+    }
+}
+
+// The step with mlp1's output layer and mlp2's input layer collapsed into one product per point
+// (NerfTrainerConfig.fuse_linear_pair).  W2a = mlp1.W2 [M][H], W1b = mlp2.W1 [H][M]:
+//   Wc = W1b W2a [H][H];  forward   pre2 = act1 Wc^T
+//   backward  dWc = dpre2^T act1;  dW1b (+)= dWc W2a^T;  dW2a (+)= W1b^T dWc;
+//             dpre1 = (dpre2 Wc) .* swish'(pre1)
+// The three H x H x M products are exact fp32 whatever the MLPs' matrix arithmetic.
+int after_forward_fused(NerfTrainer* tr, int accumulate) {
+    MLP *m1 = tr->mlp1, *m2 = tr->mlp2;
+    const long N = m1->batch_size;
+    const int H = m1->hidden_dim, M = m1->output_dim, O = m2->output_dim, math = m1->matrix_math;
+    const double small = 2.0 * H * H * (double)M;
+    {
+        ProfScope prof(K_GEMM_FWD, small);
+        GemmArgs g = {};
+        g.A = m2->d_W1; g.lda = M; g.a_kc = 1;
+        g.B = m1->d_W2; g.ldb = H; g.b_kc = 0;
+        g.C = tr->d_wc; g.ldc = H; g.M = H; g.N = H; g.K = M; g.epilogue = EPI_STORE;
+        must(gemm_f32(g), "Wc = W1b W2a");
+    }
+    const PitchedInput in = encoded_input(tr);
+    {
+        ProfScope prof(K_GEMM_FWD, 2.0 * (double)N * H * m1->input_dim);
+        GemmArgs g = {};
+        g.A = in.X; g.lda = in.ld; g.a_kc = 1;
+        g.B = in.W1; g.ldb = in.ld; g.b_kc = 1;
+        g.C = m1->d_layer_preact; g.C2 = m1->d_layer_postact; g.ldc = H;
+        g.M = (int)N; g.N = H; g.K = in.ld; g.epilogue = EPI_SWISH;
+        must(mlp_gemm(g, math), "layer 1");
+    }
+    {
+        ProfScope prof(K_GEMM_FWD, 2.0 * (double)N * H * H);
+        GemmArgs g = {};
+        g.A = m1->d_layer_postact; g.lda = H; g.a_kc = 1;
+        g.B = tr->d_wc; g.ldb = H; g.b_kc = 1;
+        g.C = m2->d_layer_preact; g.C2 = m2->d_layer_postact; g.ldc = H;
+        g.M = (int)N; g.N = H; g.K = H; g.epilogue = EPI_SWISH;
+        must(mlp_gemm(g, math), "fused pair, forward");
+    }
+    skinny_forward(m2->d_layer_postact, m2->d_W2, m2->d_layer_output, N, H, O);
+    const int rc = composite_and_gradient(tr, m2->d_layer_output, m2->d_error_output, accumulate);
+    if (rc != NERF_OK) return rc;
+    skinny_backward(m2->d_error_output, m2->d_layer_preact, m2->d_W2, m2->d_error_hidden, m2->d_W2_grad, N, H, O,
+                    m2->d_workspace, accumulate);
+    weight_gradient(m2->d_error_hidden, H, m1->d_layer_postact, H, H, N, tr->d_dwc, tr->d_pair_ws, 0, math);
+    {
+        ProfScope prof(K_GEMM_WGRAD, 2.0 * small);
+        GemmArgs g = {};  // dW1b [H][M] = dWc [H][H] * W2a[M][H]^T
+        g.A = tr->d_dwc; g.lda = H; g.a_kc = 1;
+        g.B = m1->d_W2; g.ldb = H; g.b_kc = 1;
+        g.C = accumulate ? tr->d_pair_tmp : m2->d_W1_grad; g.ldc = M; g.M = H; g.N = M; g.K = H; g.epilogue = EPI_STORE;
+        must(gemm_f32(g), "dW1b = dWc W2a^T");
+        if (accumulate) reduce_slabs(tr->d_pair_tmp, 1, (size_t)H * M, m2->d_W1_grad, (size_t)H * M, 1);
+        GemmArgs h = {};  // dW2a [M][H] = W1b[H][M]^T * dWc [H][H]
+        h.A = m2->d_W1; h.lda = M; h.a_kc = 0;
+        h.B = tr->d_dwc; h.ldb = H; h.b_kc = 0;
+        h.C = accumulate ? tr->d_pair_tmp : m1->d_W2_grad; h.ldc = H; h.M = M; h.N = H; h.K = H; h.epilogue = EPI_STORE;
+        must(gemm_f32(h), "dW2a = W1b^T dWc");
+        if (accumulate) reduce_slabs(tr->d_pair_tmp, 1, (size_t)M * H, m1->d_W2_grad, (size_t)M * H, 1);
+    }
+    {
+        ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)N * H * H);
+        GemmArgs g = {};
+        g.A = m2->d_error_hidden; g.lda = H; g.a_kc = 1;
+        g.B = tr->d_wc; g.ldb = H; g.b_kc = 0;
+        g.C = m1->d_error_hidden; g.AUX = m1->d_layer_preact; g.ldc = H;
+        g.M = (int)N; g.N = H; g.K = H; g.epilogue = EPI_DSWISH_MUL;
+        must(mlp_gemm(g, math), "fused pair, backward");
+    }
+    weight_gradient(m1->d_error_hidden, H, tr->d_pe, m1->input_dim, tr->pe_ld, N, m1->d_W1_grad, m1->d_workspace,
+                    accumulate, math);
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
 int after_forward(NerfTrainer* tr, int accumulate) {
     if (tr->bf) return after_forward_bf16(tr, accumulate);
+    if (tr->cfg.fuse_linear_pair) return after_forward_fused(tr, accumulate);
     mlp_forward(tr->mlp1, encoded_input(tr));
     mlp_forward(tr->mlp2, tr->mlp1->d_layer_output);
     const int rc = composite_and_gradient(tr, tr->mlp2->d_layer_output, tr->mlp2->d_error_output, accumulate);
@@ -162,6 +249,7 @@ void nerf_trainer_default_config(NerfTrainerConfig* cfg) {
     cfg->learning_rate = NERF_DEFAULT_LR;
     cfg->precision = NERF_PRECISION_F32;
     cfg->quadrature = NERF_QUADRATURE_REFERENCE;
+    cfg->fuse_linear_pair = 0;
 }
 
 size_t nerf_trainer_param_count(const NerfTrainerConfig* c) {
@@ -180,6 +268,8 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
         return nullptr;
     if (cfg->quadrature != NERF_QUADRATURE_REFERENCE && cfg->quadrature != NERF_QUADRATURE_SPACING) return nullptr;
     const bool bf16 = cfg->precision == NERF_PRECISION_BF16;
+    if (cfg->fuse_linear_pair != 0 && cfg->fuse_linear_pair != 1) return nullptr;
+    if (cfg->fuse_linear_pair && (bf16 || !skinny_ok(cfg->hidden_dim, cfg->output_dim))) return nullptr;
     if (bf16 && !bf16_step_supported(NERF_PE_DIM3(cfg->pos_enc_l) + NERF_PE_DIM3(cfg->dir_enc_l), cfg->hidden_dim,
                                      cfg->intermediate_dim, cfg->output_dim))
         return nullptr;
@@ -210,6 +300,12 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
     dalloc(&tr->d_target, (size_t)R * 3);
     dalloc(&tr->d_pixel, (size_t)R * 3);
     dalloc(&tr->d_err, (size_t)R * 3);
+    if (cfg->fuse_linear_pair) {
+        dalloc(&tr->d_wc, (size_t)H * H);
+        dalloc(&tr->d_dwc, (size_t)H * H);
+        dalloc(&tr->d_pair_tmp, (size_t)H * M);
+        dalloc(&tr->d_pair_ws, wgrad_slab_bytes(H, H, N) / sizeof(float));
+    }
     if (ok) {
         float *P = tr->d_params, *G = tr->d_grads, *Mo = tr->d_m, *V = tr->d_v;
         const size_t* o = tr->off;
@@ -247,6 +343,7 @@ void nerf_trainer_destroy(NerfTrainer* tr) {
     if (tr->owns_grads) hipFree(tr->d_grads);
     hipFree(tr->d_m); hipFree(tr->d_v); hipFree(tr->d_pe); hipFree(tr->d_w1p);
     hipFree(tr->d_target); hipFree(tr->d_pixel); hipFree(tr->d_err);
+    hipFree(tr->d_wc); hipFree(tr->d_dwc); hipFree(tr->d_pair_tmp); hipFree(tr->d_pair_ws);
     free(tr);
 }
 

@@ -1,0 +1,115 @@
+"""GPU tests of NerfTrainerConfig.fuse_linear_pair: mlp1's output layer and mlp2's input layer have no
+activation between them (reference train.c:189), so the step may run ONE product per point through
+Wc = W1b W2a where the reference runs two, and derive both layers' gradients from dWc.  The bar: the
+same oracle parity as the plain step, and agreement with the plain step to fp32 rounding."""
+import numpy as np
+import pytest
+
+from test_gpu_trainer import REL, Pair, norm_close, pix_close
+
+pytestmark = pytest.mark.gpu
+
+ROUNDING = 2e-5   # plain vs fused: the same sums associated differently, through three layers
+
+
+def _both(gpu, oracle, R, S, precision=0, **kw):
+    plain = Pair(gpu, oracle, R, S, precision=precision, **kw)
+    fused = Pair(gpu, oracle, R, S, precision=precision, fuse_linear_pair=1, **kw)
+    fused.tr.set_params(plain.tr.get_params())
+    return plain, fused
+
+
+@pytest.mark.parametrize("precision", [0, 2])
+def test_reference_config_step_matches_oracle_and_plain_step(gpu, oracle, precision):
+    from nerf_amd.api import DeviceArray, Trainer
+    plain, fused = _both(gpu, oracle, 16, 128, precision=precision)
+    idx = plain.indices(1)
+    d_idx = DeviceArray.from_numpy(idx)
+    plain.tr.forward_backward(plain.dds, d_idx)
+    fused.tr.forward_backward(fused.dds, d_idx)
+    _, _, o_loss = fused.oracle_step(idx, literal=True)
+    st = oracle.step_arrays(fused.buf)
+
+    # against the oracle: the plain step's bars
+    norm_close(fused.tr.buffer(Trainer.BUF_RAW), fused.a2["layer_output"])
+    np.testing.assert_allclose(fused.tr.buffer(Trainer.BUF_PIXEL), st["pixel"], rtol=REL, atol=2e-6 if precision == 0 else 2e-5)
+    grads, sse = fused.tr.get_grads()
+    assert sse == pytest.approx(o_loss, rel=REL)
+    og = fused.oracle_grads()
+    for (off, shape) in fused.tr.param_slices():
+        n = shape[0] * shape[1]
+        norm_close(grads[off:off + n], og[off:off + n])
+
+    # against the plain step
+    tol = ROUNDING if precision == 0 else 5e-5
+    pgrads, psse = plain.tr.get_grads()
+    norm_close(fused.tr.buffer(Trainer.BUF_RAW), plain.tr.buffer(Trainer.BUF_RAW), tol)
+    assert sse == pytest.approx(psse, rel=tol)
+    for (off, shape) in fused.tr.param_slices():
+        n = shape[0] * shape[1]
+        norm_close(grads[off:off + n], pgrads[off:off + n], tol)
+    assert not np.array_equal(grads, pgrads)   # it really is a different order of operations
+
+    lr = 1e-4 * 0.99
+    fused.tr.update(lr)
+    oracle.update(fused.m1, lr)
+    oracle.update(fused.m2, lr)
+    assert np.abs(fused.tr.get_params() - fused.oracle_params()).max() <= (2e-3 if precision == 0 else 2e-2) * lr
+
+
+def test_other_widths_and_sample_counts(gpu, oracle_fast):
+    """hidden != intermediate (Wc is hidden x hidden, the derived gradients hidden x intermediate), ragged S"""
+    from nerf_amd.api import DeviceArray
+    for (R, S, Lp, Ld, hidden, inter) in [(8, 64, 4, 2, 128, 64), (5, 100, 16, 8, 256, 512)]:
+        p = Pair(gpu, oracle_fast, R, S, Lp, Ld, hidden, inter, fuse_linear_pair=1)
+        idx = p.indices(R * S)
+        p.tr.forward_backward(p.dds, DeviceArray.from_numpy(idx))
+        _, _, o_loss = p.oracle_step(idx, literal=False)
+        grads, sse = p.tr.get_grads()
+        assert sse == pytest.approx(o_loss, rel=REL)
+        og = p.oracle_grads()
+        for (off, shape) in p.tr.param_slices():
+            n = shape[0] * shape[1]
+            norm_close(grads[off:off + n], og[off:off + n], 2e-4)
+
+
+def test_micro_batches_accumulate(gpu, oracle_fast):
+    """forward_backward + forward_backward_add on two halves = one full batch (the derived gradients
+    are added to the arena, not overwritten)"""
+    from nerf_amd.api import DeviceArray
+    R, S = 64, 128
+    full = Pair(gpu, oracle_fast, R, S, fuse_linear_pair=1)
+    half = Pair(gpu, oracle_fast, R // 2, S, fuse_linear_pair=1)
+    half.tr.set_params(full.tr.get_params())
+    idx = full.indices(9)
+    full.tr.forward_backward(full.dds, DeviceArray.from_numpy(idx))
+    g_full, sse_full = full.tr.get_grads()
+    half.tr.forward_backward(half.dds, DeviceArray.from_numpy(np.ascontiguousarray(idx[:R // 2])))
+    half.tr.forward_backward_add(half.dds, DeviceArray.from_numpy(np.ascontiguousarray(idx[R // 2:])))
+    g_sum, sse_sum = half.tr.get_grads()
+    assert sse_sum == pytest.approx(sse_full, rel=1e-5)
+    for (off, shape) in full.tr.param_slices():
+        n = shape[0] * shape[1]
+        norm_close(g_sum[off:off + n], g_full[off:off + n], ROUNDING)
+
+
+def test_three_steps_stay_with_the_plain_trainer(gpu, oracle_fast):
+    from nerf_amd.api import DeviceArray
+    plain, fused = _both(gpu, oracle_fast, 32, 128)
+    for step in range(3):
+        d_idx = DeviceArray.from_numpy(plain.indices(50 + step))
+        plain.tr.step(plain.dds, d_idx)
+        fused.tr.step(fused.dds, d_idx)
+        assert fused.tr.last_loss() == pytest.approx(plain.tr.last_loss(), rel=1e-4)
+    lr = plain.tr.learning_rate()
+    # AdamW normalises the step: agreement of the weights to a fraction of lr = agreement of the steps
+    assert np.abs(fused.tr.get_params() - plain.tr.get_params()).max() <= 0.05 * lr
+
+
+def test_create_rejects_unsupported_combinations(gpu):
+    from nerf_amd._lib import lib
+    from nerf_amd.api import trainer_config
+    import ctypes as C
+    for kw in (dict(fuse_linear_pair=1, precision=1), dict(fuse_linear_pair=2), dict(fuse_linear_pair=1, hidden_dim=24)):
+        cfg = trainer_config(rays_per_batch=4, num_samples=8, **kw)
+        assert not lib.nerf_trainer_create(C.byref(cfg), None, None)

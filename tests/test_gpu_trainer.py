@@ -32,7 +32,7 @@ class Pair:
     """GPU trainer + oracle MLPs holding identical weights and one scene."""
 
     def __init__(self, gpu, oracle, R, S, Lp=16, Ld=8, hidden=512, inter=512, n_images=4, acc_f64=True, seed=11,
-                 precision=0):
+                 precision=0, **cfg_extra):
         from oracle.pyoracle import ACC_F32, ACC_F64
         from nerf_amd.api import HostDataset, Trainer, make_camera, trainer_config
         self.oracle, self.R, self.S, self.Lp, self.Ld = oracle, R, S, Lp, Ld
@@ -41,7 +41,7 @@ class Pair:
         self.ocams = [oracle.camera(*c) for c in cams]
         self.dds = self.host.upload()
         cfg = trainer_config(rays_per_batch=R, num_samples=S, pos_enc_l=Lp, dir_enc_l=Ld, hidden_dim=hidden,
-                             intermediate_dim=inter, precision=precision)
+                             intermediate_dim=inter, precision=precision, **cfg_extra)
         self.tr = Trainer(cfg)
         pe = self.tr.pe_dim
         parts, flat = flat_params(oracle, pe, hidden, inter, 4, seed)
