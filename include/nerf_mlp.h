@@ -50,7 +50,8 @@ typedef struct {
     int t; /* number of update_weights_mlp calls so far */
     /* activations and errors (device), all [batch_size][...] */
     float* d_layer_preact;  /* X W1^T            [hidden_dim] */
-    float* d_layer_postact; /* swish of the above [hidden_dim] */
+    float* d_layer_postact; /* swish of the above [hidden_dim]; NOT written when output_dim <= 4: the narrow
+                             * output layer applies the activation itself as it streams the pre-activation */
     float* d_layer_output;  /* Y                  [output_dim] */
     float* d_error_hidden;  /* EH                 [hidden_dim] */
     float* d_error_output;  /* E, written by the caller before backward_pass_mlp [output_dim] */

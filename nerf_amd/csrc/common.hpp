@@ -123,8 +123,9 @@ int weight_gradient_bf16(const bf16_t* Err, int rows_out, int ld_err, const bf16
 int convert_to_bf16(const float* src, int rows, int cols, int ld_src, bf16_t* dst, int ld_dst, int transpose);
 
 // ---- skinny (output_dim <= 4) layers -----------------------------------------------------------
-// Y[n][o] = sum_h Hact[n][h] * W2[o][h]
-void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim);
+// Y[n][o] = sum_h Hact[n][h] * W2[o][h];  from_preact: Hact holds the pre-activation, swish is applied on load
+void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim,
+                    bool from_preact = false);
 // EH[n][h] = (sum_o E[n][o] W2[o][h]) * swish'(Hpre[n][h]);  dW2[o][h] (+)= sum_n E[n][o] * swish(Hpre[n][h])
 // workspace: at least skinny_backward_workspace(rows, hidden, out_dim) bytes
 size_t skinny_backward_workspace(long rows, int hidden, int out_dim);

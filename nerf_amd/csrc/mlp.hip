@@ -25,7 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // skinny forward: 16 lanes per point, 4 points per wavefront, W2 staged in LDS once per workgroup
 // ------------------------------------------------------------------------------------------------
-template <int OUT>
+// PRE: the input is the PRE-activation and swish is applied on the way in (same hardware exp2/rcp
+// sigmoid as the matrix products' swish epilogue, so the values are the ones that epilogue would have
+// stored) -- the producing product then need not write the activated copy at all.
+template <int OUT, bool PRE>
 __global__ __launch_bounds__(256) void skinny_forward_kernel(const float* __restrict__ Hact,
                                                              const float* __restrict__ W2, float* __restrict__ Y,
                                                              long rows, int hidden) {
@@ -41,7 +44,12 @@ __global__ __launch_bounds__(256) void skinny_forward_kernel(const float* __rest
 #pragma unroll
         for (int o = 0; o < OUT; o++) acc[o] = 0.f;
         for (int c = sub * 4; c < hidden; c += 64) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(h + c);
+            f32x4 x = *reinterpret_cast<const f32x4*>(h + c);
+            if (PRE) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    x[k] = x[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x[k] * -1.44269504088896340736f));
+            }
 #pragma unroll
             for (int o = 0; o < OUT; o++) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(w2s + o * hidden + c);
@@ -163,15 +171,19 @@ int skinny_backward_blocks(long rows, int hidden) {
 
 bool skinny_ok(int hidden, int out_dim) { return skinny_ok_impl(hidden, out_dim); }
 
-void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim) {
+void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim, bool from_preact) {
     ProfScope prof(K_SKINNY_FWD, (double)rows * (hidden + out_dim) * 4.0);
     long blocks = (rows + 127) / 128;  // 8 iterations of 16 points per workgroup
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     const size_t lds = (size_t)out_dim * hidden * sizeof(float);
 #define SKF(OUT)                                                                                               \
-    hipLaunchKernelGGL((skinny_forward_kernel<OUT>), dim3((unsigned)blocks), dim3(256), lds, stream(), Hact, W2, Y, \
-                       rows, hidden)
+    if (from_preact)                                                                                           \
+        hipLaunchKernelGGL((skinny_forward_kernel<OUT, true>), dim3((unsigned)blocks), dim3(256), lds, stream(), Hact, \
+                           W2, Y, rows, hidden);                                                               \
+    else                                                                                                       \
+        hipLaunchKernelGGL((skinny_forward_kernel<OUT, false>), dim3((unsigned)blocks), dim3(256), lds, stream(), Hact, \
+                           W2, Y, rows, hidden)
     switch (out_dim) {
         case 1: SKF(1); break;
         case 2: SKF(2); break;
@@ -295,12 +307,18 @@ void mlp_forward(MLP* mlp, const PitchedInput& in) {
     g.C = mlp->d_layer_preact; g.C2 = mlp->d_layer_postact; g.ldc = mlp->hidden_dim;
     g.M = (int)B; g.N = mlp->hidden_dim; g.K = in.ld;
     g.epilogue = EPI_SWISH;
+    // A narrow output layer applies swish itself while it streams the pre-activation, so layer 1 stores
+    // one matrix instead of two (forward-only MLPs keep no pre-activation: they store the activated one)
+    const bool skinny = skinny_ok(mlp->hidden_dim, mlp->output_dim);
+    const bool pre_only = skinny && mlp->d_layer_preact != nullptr;
+    if (pre_only) { g.C2 = nullptr; g.epilogue = EPI_STORE; }
     {
         ProfScope prof(K_GEMM_FWD, 2.0 * (double)B * mlp->hidden_dim * mlp->input_dim);
         if (mlp_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "forward_pass_mlp: layer 1 failed\n"); exit(EXIT_FAILURE); }
     }
-    if (skinny_ok(mlp->hidden_dim, mlp->output_dim)) {
-        skinny_forward(mlp->d_layer_postact, mlp->d_W2, mlp->d_layer_output, B, mlp->hidden_dim, mlp->output_dim);
+    if (skinny) {
+        skinny_forward(pre_only ? mlp->d_layer_preact : mlp->d_layer_postact, mlp->d_W2, mlp->d_layer_output, B,
+                       mlp->hidden_dim, mlp->output_dim, pre_only);
     } else {
         GemmArgs h = {};
         h.A = mlp->d_layer_postact; h.lda = mlp->hidden_dim; h.a_kc = 1;

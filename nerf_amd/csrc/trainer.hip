@@ -181,11 +181,11 @@ int after_forward_fused(NerfTrainer* tr, int accumulate) {
         GemmArgs g = {};
         g.A = m1->d_layer_postact; g.lda = H; g.a_kc = 1;
         g.B = tr->d_wc; g.ldb = H; g.b_kc = 1;
-        g.C = m2->d_layer_preact; g.C2 = m2->d_layer_postact; g.ldc = H;
-        g.M = (int)N; g.N = H; g.K = H; g.epilogue = EPI_SWISH;
+        g.C = m2->d_layer_preact; g.ldc = H;  // the output layer applies swish as it streams this in
+        g.M = (int)N; g.N = H; g.K = H; g.epilogue = EPI_STORE;
         must(mlp_gemm(g, math), "fused pair, forward");
     }
-    skinny_forward(m2->d_layer_postact, m2->d_W2, m2->d_layer_output, N, H, O);
+    skinny_forward(m2->d_layer_preact, m2->d_W2, m2->d_layer_output, N, H, O, true);
     const int rc = composite_and_gradient(tr, m2->d_layer_output, m2->d_error_output, accumulate);
     if (rc != NERF_OK) return rc;
     skinny_backward(m2->d_error_output, m2->d_layer_preact, m2->d_W2, m2->d_error_hidden, m2->d_W2_grad, N, H, O,

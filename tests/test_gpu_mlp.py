@@ -51,7 +51,9 @@ def test_forward_backward_update(gpu, oracle, in_dim, hid, out, batch):
     lib.forward_pass_mlp(m, d_X.ptr)
     oracle.forward(om, X)
     close(dev(mc.d_layer_preact, (batch, hid)), arr["layer_preact"], 2e-6)
-    close(dev(mc.d_layer_postact, (batch, hid)), arr["layer_postact"], 2e-6)
+    narrow = out <= 4 and hid % 4 == 0 and 256 % (hid // 4) == 0
+    if not narrow:   # a narrow output layer applies swish on the fly: the activated copy is never stored
+        close(dev(mc.d_layer_postact, (batch, hid)), arr["layer_postact"], 2e-6)
     close(dev(mc.d_layer_output, (batch, out)), arr["layer_output"], 4e-6)
 
     DeviceArray((batch, out), ptr=mc.d_error_output).upload(E)
