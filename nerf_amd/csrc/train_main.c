@@ -17,7 +17,12 @@
  * resuming from two checkpoint files with the dimension check (train.c:91-121).
  *
  *   ./train [--data DIR] [--images N] [--rays R] [--samples S] [--batches B] [--path classic|fused]
- *           [--render-every K] [--log-every K] [--seed X] [--save PREFIX] [model1.bin model2.bin]
+ *           [--render-every K] [--log-every K] [--seed X] [--save PREFIX] [--math exact|split-bf16]
+ *           [--fuse-pair 0|1] [model1.bin model2.bin]
+ *
+ * --math split-bf16 and --fuse-pair 1 are this library's opt-in speed-ups (include/nerf_amd.h:
+ * NERF_PRECISION_SPLIT_BF16, fuse_linear_pair); the defaults run the reference's arithmetic and layer
+ * arrangement.  --fuse-pair needs the device-side step (--path fused, the default).
  */
 #include <math.h>
 #include <stdio.h>
@@ -32,6 +37,7 @@
 typedef struct {
     const char* data_dir;
     int max_images, rays, samples, batches, fused, render_every, log_every;
+    int split_math, fuse_pair;
     long seed; /* < 0: srand(time(NULL)) and rand() everywhere, like train.c:13.  >= 0: repeatable run (see main) */
     const char* save_prefix;
     const char* resume[2];
@@ -47,6 +53,8 @@ static int parse_options(int argc, char** argv, Options* o) {
     o->render_every = 5000;
     o->log_every = 100;
     o->seed = -1;
+    o->split_math = 0;
+    o->fuse_pair = 0;
     o->save_prefix = NULL;
     o->resume[0] = o->resume[1] = NULL;
     int positional = 0;
@@ -65,6 +73,10 @@ static int parse_options(int argc, char** argv, Options* o) {
             else if (!strcmp(a, "--log-every")) o->log_every = atoi(v);
             else if (!strcmp(a, "--seed")) o->seed = atol(v);
             else if (!strcmp(a, "--save")) o->save_prefix = v;
+            else if (!strcmp(a, "--math")) {
+                if (!strcmp(v, "split-bf16")) o->split_math = 1;
+                else if (strcmp(v, "exact") != 0) return -1;
+            } else if (!strcmp(a, "--fuse-pair")) o->fuse_pair = atoi(v) != 0;
             else return -1;
             i++;
         } else if (positional < 2) {
@@ -183,6 +195,8 @@ int main(int argc, char** argv) {
         nerf_trainer_default_config(&cfg);
         cfg.rays_per_batch = o.rays;
         cfg.num_samples = o.samples;
+        cfg.precision = o.split_math ? NERF_PRECISION_SPLIT_BF16 : NERF_PRECISION_F32;
+        cfg.fuse_linear_pair = o.fuse_pair;
         trainer = nerf_trainer_create(&cfg, NULL, NULL);
         dds = nerf_dataset_upload(ds);
         if (!trainer || !dds) {
@@ -250,6 +264,15 @@ int main(int argc, char** argv) {
         }
     }
 
+    if (!o.fused) { /* classic call sequence: the arithmetic is a property of each MLP */
+        if (o.fuse_pair) {
+            fprintf(stderr, "--fuse-pair needs --path fused\n");
+            return -1;
+        }
+        CHECK_HIP(nerf_mlp_set_matrix_math(mlp1, o.split_math));
+        CHECK_HIP(nerf_mlp_set_matrix_math(mlp2, o.split_math));
+    }
+
     ClassicBuffers cb;
     memset(&cb, 0, sizeof(cb));
     int* idx = NULL;
@@ -264,6 +287,9 @@ int main(int argc, char** argv) {
     printf("Starting NeRF training with %d batches...\n", o.batches);
     printf("Batch size: %d rays, %d samples per ray\n", o.rays, o.samples);
     printf("Network: %d -> %d -> %d -> %d -> %d\n", pe_dim, hidden, inter, hidden, out_dim);
+    if (o.split_math || o.fuse_pair)
+        printf("Options: %s products%s\n", o.split_math ? "split-bf16" : "exact fp32",
+               o.fuse_pair ? ", linear pair fused" : "");
     printf("Positional encoding: pos_L=%d, dir_L=%d, total_dim=%d\n", NERF_DEFAULT_POS_ENC_L, NERF_DEFAULT_DIR_ENC_L,
            pe_dim);
 

@@ -67,6 +67,32 @@ def test_classic_and_fused_paths_train_the_same_model(gpu, tmp_path):
     assert read_checkpoint(tmp_path / "c_nerf_model2.bin")["dims"][:3] == (512, 512, 4)
 
 
+def test_speed_options_train_the_same_model(gpu, tmp_path):
+    """--math split-bf16 (either path) and --fuse-pair 1 (device-side step): same losses and, after four
+    AdamW steps, the same weights to a fraction of the step size"""
+    write_scene(str(tmp_path))
+    common = ["--data", str(tmp_path), "--images", "4", "--rays", "8", "--samples", "32", "--batches", "4",
+              "--seed", "3", "--log-every", "2", "--render-every", "0"]
+    loss = lambda out: [float(l.split("Loss:")[1].split(",")[0]) for l in out.splitlines() if "Loss:" in l]
+    base = run(common + ["--save", "base"], str(tmp_path))
+    lr = 1e-4 * 0.99
+    variants = {"s": ["--math", "split-bf16"], "f": ["--fuse-pair", "1"], "sf": ["--math", "split-bf16", "--fuse-pair", "1"],
+                "cs": ["--path", "classic", "--math", "split-bf16"]}
+    for tag, extra in variants.items():
+        out = run(common + extra + ["--save", tag], str(tmp_path))
+        assert "Options:" in out
+        np.testing.assert_allclose(loss(out), loss(base), rtol=5e-4)
+        for k in (1, 2):
+            a, b = read_checkpoint(tmp_path / f"base_nerf_model{k}.bin"), read_checkpoint(tmp_path / f"{tag}_nerf_model{k}.bin")
+            assert a["t"] == b["t"] == 4
+            for name in ("W1", "W2"):
+                assert np.abs(a[name] - b[name]).max() <= 0.1 * lr, (tag, k, name)
+    # the fused pair is a property of the device-side step
+    p = subprocess.run([TRAIN] + common + ["--path", "classic", "--fuse-pair", "1"], cwd=str(tmp_path), capture_output=True,
+                       text=True, timeout=110)
+    assert p.returncode != 0 and "--path fused" in p.stderr
+
+
 @pytest.mark.parametrize("path", ["classic", "fused"])
 def test_resume_continues_the_step_count_and_writes_a_render(gpu, tmp_path, path):
     write_scene(str(tmp_path))
