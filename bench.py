@@ -131,19 +131,20 @@ def render_workload(args, lib, torch):
     from nerf_amd.api import Trainer, prof_read, synthetic_dataset, trainer_config
     assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "the render workload is single-GPU"
     host = synthetic_dataset(num_images=2, width=800, height=800, seed=1234)
-    tr = Trainer(trainer_config(rays_per_batch=16, num_samples=args.samples))
+    split, fused = args.math == "split-bf16", bool(args.fuse_linear_pair)
+    tr = Trainer(trainer_config(rays_per_batch=16, num_samples=args.samples, precision=2 if split else 0))
     tr.init_weights(seed=1, use_rand=False)
     cam = host.cameras[0]
     W = H = 800
-    for _ in range(max(1, args.warmup)):
-        tr.render_view(cam, W, H, rays_per_chunk=args.rays)
+    for _ in range(max(1, min(args.warmup, 2))):
+        tr.render_view(cam, W, H, rays_per_chunk=args.rays, fuse_linear_pair=fused)
     torch.cuda.synchronize()
     lib.nerf_prof_reset()
     lib.nerf_prof_enable(1)
     steps = max(1, min(args.steps, 5))
     t0 = time.perf_counter()
     for _ in range(steps):
-        rgb8, _ = tr.render_view(cam, W, H, rays_per_chunk=args.rays)
+        rgb8, _ = tr.render_view(cam, W, H, rays_per_chunk=args.rays, fuse_linear_pair=fused)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     lib.nerf_prof_enable(0)
@@ -153,9 +154,12 @@ def render_workload(args, lib, torch):
     print(json.dumps({
         "metric": "rendered rays/s @128 samples/ray (forward only)", "value": W * H * steps / el, "unit": "rays/s",
         "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": el / steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 storage and accumulation, split-bf16 products (opt-in)" if split else "f32", "data": "synthetic",
         "config": {"workload": f"forward-only render of one {W}x{H} view, {args.samples} samples/ray, chunks of "
-                               f"{args.rays} rays, MLP 150-512-512-512-4, fp32"},
+                               f"{args.rays} rays, MLP 150-512-512-512-4, fp32"
+                               + (", split-bf16 products (opt-in)" if split else "")
+                               + (", linear pair fused (opt-in)" if fused else "")},
         "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<true, true, 2, 2, 2, 2> (forward products)",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,

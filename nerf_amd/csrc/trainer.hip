@@ -518,8 +518,17 @@ const float* nerf_trainer_buffer(NerfTrainer* tr, int which) {
 int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
                      float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
                      unsigned char* host_rgb8, float* host_pixel) {
+    return nerf_render_view_opts(mlp1, mlp2, cam, render_w, render_h, num_samples, near_plane, far_plane, pos_enc_l,
+                                 dir_enc_l, rays_per_chunk, host_rgb8, host_pixel, 0);
+}
+
+int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
+                          float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
+                          unsigned char* host_rgb8, float* host_pixel, int fuse_linear_pair) {
     if (!mlp1 || !mlp2 || !cam || render_w <= 0 || render_h <= 0 || num_samples <= 1 || num_samples > 1024)
         return NERF_ERR_ARG;
+    if (fuse_linear_pair != 0 && fuse_linear_pair != 1) return NERF_ERR_ARG;
+    if (fuse_linear_pair && !skinny_ok(mlp2->hidden_dim, mlp2->output_dim)) return NERF_ERR_ARG;
     const int pe_dim = NERF_PE_DIM3(pos_enc_l) + NERF_PE_DIM3(dir_enc_l);
     if (mlp1->input_dim != pe_dim || mlp2->input_dim != mlp1->output_dim || mlp2->output_dim < 4) return NERF_ERR_ARG;
     const int total = render_w * render_h;
@@ -537,10 +546,12 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
         r2->matrix_math = mlp2->matrix_math;
     }
     const int pe_ld = ((pe_dim + 31) / 32) * 32;  // pitched like the trainer's encoding (zero row tails)
-    float *d_pe = nullptr, *d_pixel = nullptr, *d_w1p = nullptr;
+    float *d_pe = nullptr, *d_pixel = nullptr, *d_w1p = nullptr, *d_wc = nullptr;
     unsigned char* d_rgb8 = nullptr;
     int rc = NERF_OK;
+    const int H1 = mlp1->hidden_dim, H2 = mlp2->hidden_dim, Mid = mlp1->output_dim;
     if (!r1 || !r2 || hipMalloc((void**)&d_pe, (size_t)N * pe_ld * 4) != hipSuccess ||
+        (fuse_linear_pair && hipMalloc((void**)&d_wc, (size_t)H2 * H1 * 4) != hipSuccess) ||
         (pe_ld != pe_dim && hipMalloc((void**)&d_w1p, (size_t)mlp1->hidden_dim * pe_ld * 4) != hipSuccess) ||
         hipMalloc((void**)&d_pixel, (size_t)total * 3 * 4) != hipSuccess ||
         hipMalloc((void**)&d_rgb8, (size_t)total * 3) != hipSuccess)
@@ -554,6 +565,13 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
                                             mlp1->hidden_dim, hipMemcpyDeviceToDevice, stream()));
             in.W1 = d_w1p;
         }
+        if (fuse_linear_pair) {  // Wc = W1b W2a, once per view (see after_forward_fused)
+            GemmArgs g = {};
+            g.A = mlp2->d_W1; g.lda = Mid; g.a_kc = 1;
+            g.B = mlp1->d_W2; g.ldb = H1; g.b_kc = 0;
+            g.C = d_wc; g.ldc = H1; g.M = H2; g.N = H1; g.K = Mid; g.epilogue = EPI_STORE;
+            rc = gemm_f32(g);
+        }
     }
     for (int first = 0; rc == NERF_OK && first < total; first += rays_per_chunk) {
         const int count = (total - first) < rays_per_chunk ? (total - first) : rays_per_chunk;
@@ -564,8 +582,28 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
                                   dir_enc_l, d_pe, pe_ld, nullptr);
         }
         if (rc != NERF_OK) break;
-        mlp_forward(r1, in);
-        mlp_forward(r2, r1->d_layer_output);
+        if (fuse_linear_pair) {
+            {
+                ProfScope prof(K_GEMM_FWD, 2.0 * (double)N * H1 * pe_dim);
+                GemmArgs g = {};  // act1 = swish(pe W1a^T); the pre-activation is not kept (C == nullptr)
+                g.A = in.X; g.lda = in.ld; g.a_kc = 1;
+                g.B = in.W1; g.ldb = in.ld; g.b_kc = 1;
+                g.C2 = r1->d_layer_postact; g.ldc = H1; g.M = N; g.N = H1; g.K = in.ld; g.epilogue = EPI_SWISH;
+                must(mlp_gemm(g, r1->matrix_math), "render: layer 1");
+            }
+            {
+                ProfScope prof(K_GEMM_FWD, 2.0 * (double)N * H2 * H1);
+                GemmArgs g = {};  // act2 = swish(act1 Wc^T)
+                g.A = r1->d_layer_postact; g.lda = H1; g.a_kc = 1;
+                g.B = d_wc; g.ldb = H1; g.b_kc = 1;
+                g.C2 = r2->d_layer_postact; g.ldc = H2; g.M = N; g.N = H2; g.K = H1; g.epilogue = EPI_SWISH;
+                must(mlp_gemm(g, r1->matrix_math), "render: fused pair");
+            }
+            skinny_forward(r2->d_layer_postact, r2->d_W2, r2->d_layer_output, N, H2, r2->output_dim);
+        } else {
+            mlp_forward(r1, in);
+            mlp_forward(r2, r1->d_layer_output);
+        }
         ProfScope prof(K_COMPOSITE_FWD, (double)count * num_samples * 16.0);
         rc = nerf_composite_forward(r2->d_layer_output, r2->output_dim, nullptr, 0, nullptr, nullptr,
                                     d_pixel + (size_t)first * 3, nullptr, count, num_samples);
@@ -579,7 +617,7 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
     }
     if (r1) free_mlp(r1);
     if (r2) free_mlp(r2);
-    hipFree(d_pe); hipFree(d_pixel); hipFree(d_rgb8); hipFree(d_w1p);
+    hipFree(d_pe); hipFree(d_pixel); hipFree(d_rgb8); hipFree(d_w1p); hipFree(d_wc);
     return rc;
 }
 

@@ -75,6 +75,12 @@ def test_render_view_matches_oracle(gpu, oracle, rw, rh, S, chunk):
     # chunk size is invisible
     rgb8_b, pix_b = tr.render_view(make_camera(*cams[0]), rw, rh, rays_per_chunk=rw * rh)
     assert np.array_equal(pix, pix_b) and np.array_equal(rgb8, rgb8_b)
+    # the linear pair as one product (nerf_render_view_opts): the same picture to fp32 rounding
+    rgb8_f, pix_f = tr.render_view(make_camera(*cams[0]), rw, rh, rays_per_chunk=chunk, fuse_linear_pair=True)
+    np.testing.assert_allclose(pix_f, ref, rtol=REL, atol=PIX_ATOL)
+    np.testing.assert_allclose(pix_f, pix, rtol=0, atol=2e-5)
+    assert not np.array_equal(pix_f, pix)
+    check_bytes(rgb8_f, pix_f)
 
 
 def test_empty_field_renders_black(gpu, oracle):
