@@ -43,13 +43,16 @@ SPLIT_KERNEL = {
 }
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, mode=""):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
-    command (profiles/*_pmc_summary.json, written by tools/pmc_summary.py: FETCH_SIZE doubled as
-    gfx950 needs for 16-byte-per-lane reads, WRITE_SIZE as is).  None when no summary is present:
-    counters cannot be read from inside the timed process."""
+    command (profiles/rNN_<mode>pmc_summary.json, written by tools/pmc_summary.py: FETCH_SIZE doubled
+    as gfx950 needs for 16-byte-per-lane reads, WRITE_SIZE as is; mode = "", "split_", "fused_",
+    "fused_split_" for the bench's options).  None when no summary is present: counters cannot be read
+    from inside the timed process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))
+                   if re.fullmatch(r"r\d+_" + mode + "pmc_summary\.json", os.path.basename(f)))
     if not files:
         return None, None
     for path in reversed(files):  # latest round first; a summary only holds the kernels its command ran
@@ -378,7 +381,8 @@ def main():
         achieved = dwork / (dms * 1e-3) / 1e12
         all_ms = sum(v[0] for v in gemm.values())
         all_work = sum(v[2] for v in gemm.values())
-        traffic, mfma_util = pmc_traffic((SPLIT_KERNEL if split else GEMM_KERNEL)[dom])
+        traffic, mfma_util = pmc_traffic((SPLIT_KERNEL if split else GEMM_KERNEL)[dom],
+                                          ("fused_" if fused else "") + ("split_" if split else ""))
         kernel_label = f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles, LDS-DMA staged)"
         peak = PEAK_F32_MFMA_TFLOPS
         if split:
