@@ -41,6 +41,8 @@ SPLIT_KERNEL = {
     "gemm_dgrad": "gemm_split_kernel<true, false, 2, 4, 4, 2>",
     "gemm_wgrad": "gemm_split_kernel<false, false, 2, 4, 4, 2>",
 }
+# split-bf16 with the linear pair fused: the large products read split words their producers wrote
+SPLIT_WORDS_KERNEL = {k: v[:-1] + ", true>" for k, v in SPLIT_KERNEL.items()}
 
 
 def pmc_traffic(kernel, mode=""):
@@ -381,7 +383,8 @@ def main():
         achieved = dwork / (dms * 1e-3) / 1e12
         all_ms = sum(v[0] for v in gemm.values())
         all_work = sum(v[2] for v in gemm.values())
-        traffic, mfma_util = pmc_traffic((SPLIT_KERNEL if split else GEMM_KERNEL)[dom],
+        names = (SPLIT_WORDS_KERNEL if fused else SPLIT_KERNEL) if split else GEMM_KERNEL
+        traffic, mfma_util = pmc_traffic(names[dom],
                                           ("fused_" if fused else "") + ("split_" if split else ""))
         kernel_label = f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles, LDS-DMA staged)"
         peak = PEAK_F32_MFMA_TFLOPS
@@ -390,7 +393,7 @@ def main():
             # against the bf16 matrix peak
             achieved *= 3.0
             peak = PEAK_BF16_MFMA_TFLOPS
-            kernel_label = (f"{SPLIT_KERNEL[dom]} ({dom}: 3 x v_mfma_f32_32x32x16_bf16 per product on hi/lo bf16 "
+            kernel_label = (f"{names[dom]} ({dom}: 3 x v_mfma_f32_32x32x16_bf16 per product on hi/lo bf16 "
                             "splits of the fp32 operands, 256x256x32 tiles, LDS-DMA staged; achieved = executed bf16 FLOP/s)")
         for name, entry in kernels.items():  # the streaming kernels against the HBM peak
             if "gbs" in entry:

@@ -116,11 +116,20 @@ int nerf_encode_batch(const NerfDeviceDataset* dataset, const int* d_idx, const 
 int nerf_encode_batch_bf16(const NerfDeviceDataset* dataset, const int* d_idx, const float* d_offsets, int R, int S,
                            float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, unsigned short* d_pe,
                            int ld_pe, float* d_target);
+/* nerf_encode_batch writing every encoded value x as a "split word": (bf16(x) << 16) | bf16(x - bf16(x)),
+ * both rounded to nearest even -- the two halves the split-bf16 products work with, in the 4 bytes of
+ * the float.  float(head) + float(remainder) gives x back to ~2^-17.  No counterpart in the reference. */
+int nerf_encode_batch_split(const NerfDeviceDataset* dataset, const int* d_idx, const float* d_offsets, int R, int S,
+                            float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe,
+                            float* d_target);
 /* positional_encoding (nerf.c:129-145) of one device vector of any dimension:
  * d_out [dim + 2*dim*L] */
 int nerf_encode_vector(const float* d_in, int dim, int L, float* d_out);
 /* batch_positional_encoding (nerf.c:147-162) with device pointers */
 int nerf_encode_points(const float* d_batch_X, int num_points, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe);
+/* the same, writing split words (see nerf_encode_batch_split) */
+int nerf_encode_points_split(const float* d_batch_X, int num_points, int pos_enc_l, int dir_enc_l, float* d_pe,
+                             int ld_pe);
 /* the per-pixel ray set-up of render_test_image (nerf.c:259-280) for pixels
  * [first_pixel, first_pixel + num_pixels) of a render_w x render_h image, row-major */
 int nerf_encode_view(const Camera* cam, int render_w, int render_h, int first_pixel, int num_pixels, int S,

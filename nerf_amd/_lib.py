@@ -124,6 +124,9 @@ _SIGS = {
                                          C.c_int, VP]),
     "nerf_encode_vector": (C.c_int, [VP, C.c_int, C.c_int, VP]),
     "nerf_encode_points": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, C.c_int]),
+    "nerf_encode_points_split": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, C.c_int]),
+    "nerf_encode_batch_split": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, VP,
+                                          C.c_int, VP]),
     "nerf_encode_view": (C.c_int, [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_float, C.c_int, C.c_int, VP, C.c_int, VP]),
     # compositing

@@ -74,6 +74,11 @@ struct GemmArgs {
     int splits;       // EPI_SPLITK: number of contraction chunks (C = slabs base, chunk s at C + s*M*ldc)
     int k_chunk;      // EPI_SPLITK: contraction rows per chunk (multiple of 32)
     int tile_n;       // EPI_SPLITK: output tile width the caller planned with (128, 160; 256: split-bf16 only)
+    // split-bf16 kernels only.  A "split word" holds one value as (bf16 head << 16) | bf16 remainder --
+    // the two halves the split-bf16 product works with, in the 4 bytes of the float they came from.
+    int operands_split;  // A and B hold split words: the loop only unpacks them
+    int c_split;         // store C as split words (EPI_STORE, EPI_DSWISH_MUL)
+    int c2_split;        // store C2 as split words (EPI_SWISH)
 };
 
 // How a matrix product forms a*b from its fp32 operands.
@@ -130,7 +135,10 @@ void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int
 // workspace: at least skinny_backward_workspace(rows, hidden, out_dim) bytes
 size_t skinny_backward_workspace(long rows, int hidden, int out_dim);
 void skinny_backward(const float* E, const float* Hpre, const float* W2, float* EH, float* dW2, long rows,
-                     int hidden, int out_dim, float* workspace, int accumulate);
+                     int hidden, int out_dim, float* workspace, int accumulate, bool eh_split = false);
+
+// dst[i] = split word of src[i] (in place allowed)
+void to_split_words(const float* src, float* dst, size_t n);
 
 // ---- AdamW -------------------------------------------------------------------------------------
 void adamw_update(float* w, const float* g, float* m, float* v, size_t n, float grad_div, float beta1,

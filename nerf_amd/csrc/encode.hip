@@ -43,6 +43,7 @@ struct DeviceCamera {  // same layout as Camera (include/nerf_data.h)
 static_assert(sizeof(DeviceCamera) == sizeof(Camera), "Camera layout");
 
 enum { SRC_INDICES = 0, SRC_POINTS = 1, SRC_VIEW = 2 };
+enum { PE_F32 = 0, PE_BF16 = 1, PE_SPLIT = 2 };
 
 struct EncodeArgs {
     int source;
@@ -62,7 +63,8 @@ struct EncodeArgs {
     float near_plane, far_plane;
     int pos_l, dir_l;
     float* pe;                          // [N][ld_pe]
-    int pe_bf16;                        // pe points at 16-bit bf16 values (rounded to nearest even) instead of floats
+    int pe_format;                      // PE_F32; PE_BF16: pe points at 16-bit bf16 values (rounded to nearest even);
+                                        // PE_SPLIT: 32-bit split words (bf16 head << 16 | bf16 remainder)
     int ld_pe;
     float* target;                      // [R][3] or null (SRC_INDICES only)
     float* batch_X_out;                 // [N][6] or null: also emit the raw samples
@@ -94,11 +96,16 @@ __device__ __forceinline__ float sample_depth(int s, int S, float near_plane, fl
 }
 
 // one encoded value: fp32 as is, or rounded to bf16 when the buffer is 16-bit
-template <bool BF16>
+template <int BF16>
 __device__ __forceinline__ void put(float* base, size_t index, float v) {
-    if (BF16) {
+    if (BF16 == PE_BF16) {
         const __bf16 b = (__bf16)v;
         reinterpret_cast<unsigned short*>(base)[index] = __builtin_bit_cast(unsigned short, b);
+    } else if (BF16 == PE_SPLIT) {
+        const __bf16 h = (__bf16)v;
+        const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, h) << 16;
+        const __bf16 l = (__bf16)(v - __builtin_bit_cast(float, hb));
+        reinterpret_cast<unsigned*>(base)[index] = hb | (unsigned)__builtin_bit_cast(unsigned short, l);
     } else {
         base[index] = v;
     }
@@ -110,7 +117,7 @@ __device__ __forceinline__ void put(float* base, size_t index, float v) {
 // (octave, coordinate) sin/cos pair -- so that a wavefront's stores run along an encoding row.
 constexpr int ENC_POINTS = 64;
 
-template <bool BF16>
+template <int BF16>
 __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a) {
     __shared__ float sample[ENC_POINTS][6];
     const long long n_points = (long long)a.R * a.S;
@@ -213,10 +220,12 @@ int launch_encode(const EncodeArgs& a) {
     if (a.pe && a.ld_pe < NERF_PE_DIM3(a.pos_l) + NERF_PE_DIM3(a.dir_l)) return NERF_ERR_ARG;
     const long long grid = ((long long)a.R * a.S + ENC_POINTS - 1) / ENC_POINTS;
     if (grid > 0x7fffffffLL) return NERF_ERR_ARG;
-    if (a.pe_bf16)
-        hipLaunchKernelGGL(encode_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
+    if (a.pe_format == PE_BF16)
+        hipLaunchKernelGGL(encode_kernel<PE_BF16>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
+    else if (a.pe_format == PE_SPLIT)
+        hipLaunchKernelGGL(encode_kernel<PE_SPLIT>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
     else
-        hipLaunchKernelGGL(encode_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
+        hipLaunchKernelGGL(encode_kernel<PE_F32>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
@@ -296,6 +305,20 @@ int nerf_encode_batch(const NerfDeviceDataset* dds, const int* d_idx, const floa
     return launch_encode(a);
 }
 
+// nerf_encode_batch writing the encoding as split words (the split-bf16 products' pre-split operands)
+int nerf_encode_batch_split(const NerfDeviceDataset* dds, const int* d_idx, const float* d_offsets, int R, int S,
+                            float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe,
+                            float* d_target) {
+    if (!dds || !d_idx || !d_pe) return NERF_ERR_ARG;
+    if (d_target && !dds->d_pixels) return NERF_ERR_ARG;
+    EncodeArgs a = {};
+    a.source = SRC_INDICES;
+    a.cams = dds->d_cams; a.pixels = dds->d_pixels; a.img_off = dds->d_img_off; a.idx = d_idx;
+    a.offsets = d_offsets; a.R = R; a.S = S; a.near_plane = near_plane; a.far_plane = far_plane;
+    a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = d_pe; a.pe_format = PE_SPLIT; a.ld_pe = ld_pe; a.target = d_target;
+    return launch_encode(a);
+}
+
 // nerf_encode_batch with the encoding rounded to bf16 (the reduced-precision trainer's input)
 int nerf_encode_batch_bf16(const NerfDeviceDataset* dds, const int* d_idx, const float* d_offsets, int R, int S,
                            float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, unsigned short* d_pe,
@@ -306,7 +329,7 @@ int nerf_encode_batch_bf16(const NerfDeviceDataset* dds, const int* d_idx, const
     a.source = SRC_INDICES;
     a.cams = dds->d_cams; a.pixels = dds->d_pixels; a.img_off = dds->d_img_off; a.idx = d_idx;
     a.offsets = d_offsets; a.R = R; a.S = S; a.near_plane = near_plane; a.far_plane = far_plane;
-    a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = reinterpret_cast<float*>(d_pe); a.pe_bf16 = 1; a.ld_pe = ld_pe;
+    a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = reinterpret_cast<float*>(d_pe); a.pe_format = PE_BF16; a.ld_pe = ld_pe;
     a.target = d_target;
     return launch_encode(a);
 }
@@ -326,6 +349,17 @@ int nerf_encode_points(const float* d_batch_X, int num_points, int pos_enc_l, in
     a.batch_X = d_batch_X;
     a.R = num_points; a.S = 1;  // points carry their own positions: no ray sampling
     a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = d_pe; a.ld_pe = ld_pe;
+    return launch_encode(a);
+}
+
+int nerf_encode_points_split(const float* d_batch_X, int num_points, int pos_enc_l, int dir_enc_l, float* d_pe,
+                             int ld_pe) {
+    if (!d_batch_X || !d_pe) return NERF_ERR_ARG;
+    EncodeArgs a = {};
+    a.source = SRC_POINTS;
+    a.batch_X = d_batch_X;
+    a.R = num_points; a.S = 1;
+    a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = d_pe; a.pe_format = PE_SPLIT; a.ld_pe = ld_pe;
     return launch_encode(a);
 }
 

@@ -28,6 +28,15 @@ __device__ __forceinline__ float dswish_f(float x) {
     return sg * (1.0f + x * (1.0f - sg));
 }
 
+// ---- split words ------------------------------------------------------------------------------------
+// x -> (bf16(x) << 16) | bf16(x - bf16(x)), both rounded to nearest even; x - bf16(x) is exact
+__device__ __forceinline__ unsigned split_word(float x) {
+    const __bf16 h = (__bf16)x;
+    const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, h) << 16;
+    const __bf16 l = (__bf16)(x - __builtin_bit_cast(float, hb));
+    return hb | (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+
 // ---- block -> (tile_m, tile_n, split) -----------------------------------------------------------
 // Blocks b and b+8 share an XCD (and its L2): consecutive slots of one XCD walk the tiles that
 // re-read the same operand panel (the n-tiles of one row panel; the tiles of one split).
@@ -164,8 +173,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[MI][NI
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
-                    __builtin_amdgcn_raw_buffer_store_b32(
-                        __builtin_bit_cast(unsigned, acc[mi][ni][r] * dswish_f(aux[r])), rC, voff[ni], soff, 0);
+                    const float o = acc[mi][ni][r] * dswish_f(aux[r]);
+                    __builtin_amdgcn_raw_buffer_store_b32(p.c_split ? split_word(o) : __builtin_bit_cast(unsigned, o), rC,
+                                                          voff[ni], soff, 0);
                 }
             }
         }
@@ -178,10 +188,14 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[MI][NI
                 for (int r = 0; r < 16; r++) {
                     const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
                     const float x = acc[mi][ni][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x), rC, voff[ni], soff, 0);
-                    if (p.epilogue == EPI_SWISH)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, swish_f(x)), rC2, voff[ni],
-                                                              soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        p.c_split && p.epilogue == EPI_STORE ? split_word(x) : __builtin_bit_cast(unsigned, x), rC,
+                        voff[ni], soff, 0);
+                    if (p.epilogue == EPI_SWISH) {
+                        const float a = swish_f(x);
+                        __builtin_amdgcn_raw_buffer_store_b32(p.c2_split ? split_word(a) : __builtin_bit_cast(unsigned, a),
+                                                              rC2, voff[ni], soff, 0);
+                    }
                 }
             }
         }

@@ -51,6 +51,21 @@ __device__ __forceinline__ SplitFrag split8(const float (&x)[8]) {
     return f;
 }
 
+// the same from eight split words (operands a producer has already split): two byte permutes per pair
+__device__ __forceinline__ SplitFrag unpack8(const float (&x)[8]) {
+    u32x4 h, l;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const unsigned w0 = __builtin_bit_cast(unsigned, x[2 * p]), w1 = __builtin_bit_cast(unsigned, x[2 * p + 1]);
+        h[p] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);  // upper halves: the bf16 heads
+        l[p] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);  // lower halves: the bf16 remainders
+    }
+    SplitFrag f;
+    f.hi = __builtin_bit_cast(bf16x8, h);
+    f.lo = __builtin_bit_cast(bf16x8, l);
+    return f;
+}
+
 // raw[0..3] / raw[4..7]: the 8-step groups 2g and 2g+1 of a staged tile.  Lane l therefore holds
 // k = 16g + 4(l >> 5) + {0..3} and 16g + 8 + 4(l >> 5) + {0..3}: the same set for both operands,
 // which is all the 16-step MFMA needs (a fixed permutation of the summation order).
@@ -63,7 +78,7 @@ __device__ __forceinline__ void read16(float (&raw)[8], const float* __restrict_
     for (int j = 0; j < 4; j++) { raw[j] = a[j]; raw[4 + j] = b[j]; }
 }
 
-template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int CUR>
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int CUR, bool WORDS>
 __device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 * BK],
                                        const DmaLoader<A_KC, WM * MI * 32, WM * WN * 64>& da,
                                        const DmaLoader<B_KC, WN * NI * 32, WM * WN * 64>& db, f32x16 (&acc)[MI][NI],
@@ -82,9 +97,9 @@ __device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 
     for (int g = 0; g < BK / 16; g++) {
         SplitFrag sa[MI], sb[NI];
 #pragma unroll
-        for (int i = 0; i < MI; i++) sa[i] = split8(ra[i]);
+        for (int i = 0; i < MI; i++) sa[i] = WORDS ? unpack8(ra[i]) : split8(ra[i]);
 #pragma unroll
-        for (int i = 0; i < NI; i++) sb[i] = split8(rb[i]);
+        for (int i = 0; i < NI; i++) sb[i] = WORDS ? unpack8(rb[i]) : split8(rb[i]);
         if (g + 1 < BK / 16) {
 #pragma unroll
             for (int i = 0; i < MI; i++) read16<A_KC, BM_>(ra[i], TA, wm * MI * 32 + i * 32, g + 1, lane);
@@ -105,7 +120,7 @@ __device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 
     __syncthreads();
 }
 
-template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI>
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, bool WORDS = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_split_kernel(const KernelArgs ka) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32;
@@ -142,10 +157,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 4 ? 2 : 1) void gemm_split
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nkt; kt += 2) {
-        k_tile<A_KC, B_KC, WM, WN, MI, NI, 0>(lds, da, db, acc, kt + 1, wave, wm, wn, lane);
-        k_tile<A_KC, B_KC, WM, WN, MI, NI, 1>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, wm, wn, lane);
+        k_tile<A_KC, B_KC, WM, WN, MI, NI, 0, WORDS>(lds, da, db, acc, kt + 1, wave, wm, wn, lane);
+        k_tile<A_KC, B_KC, WM, WN, MI, NI, 1, WORDS>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, wm, wn, lane);
     }
-    if (kt < nkt) k_tile<A_KC, B_KC, WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, wm, wn, lane);
+    if (kt < nkt) k_tile<A_KC, B_KC, WM, WN, MI, NI, 0, WORDS>(lds, da, db, acc, kt, wave, wm, wn, lane);
     epilogue<MI, NI>(p, acc, m0, n0, split, wm * MI * 32, wn * NI * 32, lane, BM_);
 }
 
@@ -158,10 +173,21 @@ SPLIT_SHAPES(true, false)
 SPLIT_SHAPES(false, false)
 #undef SPLIT_SHAPES
 template __global__ void gemm_split_kernel<false, false, 4, 1, 1, 5>(const KernelArgs);
+// operands already in split words: the shapes the trainer's large products take
+template __global__ void gemm_split_kernel<true, true, 2, 4, 4, 2, true>(const KernelArgs);
+template __global__ void gemm_split_kernel<true, false, 2, 4, 4, 2, true>(const KernelArgs);
+template __global__ void gemm_split_kernel<false, false, 2, 4, 4, 2, true>(const KernelArgs);
+template __global__ void gemm_split_kernel<false, false, 4, 1, 1, 5, true>(const KernelArgs);
 
 template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI>
 void launch(const KernelArgs& ka, int grid) {
     hipLaunchKernelGGL((gemm_split_kernel<A_KC, B_KC, WM, WN, MI, NI>), dim3(grid), dim3(WM * WN * 64), 0, stream(), ka);
+}
+
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI>
+void launch_words(const KernelArgs& ka, int grid) {
+    hipLaunchKernelGGL((gemm_split_kernel<A_KC, B_KC, WM, WN, MI, NI, true>), dim3(grid), dim3(WM * WN * 64), 0, stream(),
+                       ka);
 }
 
 template <bool A_KC, bool B_KC>
@@ -230,7 +256,13 @@ int gemm_split(const GemmArgs& g) {
     if (splitk) grid *= g.splits;
     if (grid > 0x7fffffffL) return NERF_ERR_ARG;
     const int gi = (int)grid;
-    if (wide) launch<false, false, 4, 1, 1, 5>(ka, gi);
+    if (g.operands_split) {  // built for the large shapes only
+        if (wide) launch_words<false, false, 4, 1, 1, 5>(ka, gi);
+        else if (!big) return NERF_ERR_ARG;
+        else if (g.a_kc && g.b_kc) launch_words<true, true, 2, 4, 4, 2>(ka, gi);
+        else if (g.a_kc) launch_words<true, false, 2, 4, 4, 2>(ka, gi);
+        else launch_words<false, false, 2, 4, 4, 2>(ka, gi);
+    } else if (wide) launch<false, false, 4, 1, 1, 5>(ka, gi);
     else if (g.a_kc && g.b_kc) launch_shape<true, true>(ka, gi, big);
     else if (g.a_kc) launch_shape<true, false>(ka, gi, big);
     else launch_shape<false, false>(ka, gi, big);

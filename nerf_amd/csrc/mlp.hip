@@ -22,6 +22,19 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// x -> (bf16(x) << 16) | bf16(x - bf16(x)): the "split word" of the split-bf16 products (common.hpp)
+__device__ __forceinline__ float split_word_f(float x) {
+    const __bf16 h = (__bf16)x;
+    const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, h) << 16;
+    const __bf16 l = (__bf16)(x - __builtin_bit_cast(float, hb));
+    return __builtin_bit_cast(float, hb | (unsigned)__builtin_bit_cast(unsigned short, l));
+}
+
+__global__ __launch_bounds__(256) void split_words_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = split_word_f(src[i]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // skinny forward: 16 lanes per point, 4 points per wavefront, W2 staged in LDS once per workgroup
 // ------------------------------------------------------------------------------------------------
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(256) void skinny_forward_kernel(const float* __rest
 // skinny backward: thread = 4 hidden columns; a workgroup walks a contiguous chunk of points,
 // 256/(hidden/4) points at a time, keeps its dW2 partial in registers and writes one slab.
 // ------------------------------------------------------------------------------------------------
-template <int OUT>
+template <int OUT, bool EH_WORDS>
 __global__ __launch_bounds__(256) void skinny_backward_kernel(const float* __restrict__ E,
                                                               const float* __restrict__ Hpre,
                                                               const float* __restrict__ W2, float* __restrict__ EH,
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(256) void skinny_backward_kernel(const float* __res
             float back = e[0] * w2[0][k];
 #pragma unroll
             for (int o = 1; o < OUT; o++) back += e[o] * w2[o][k];
-            eh[k] = back * d;
+            eh[k] = EH_WORDS ? split_word_f(back * d) : back * d;
 #pragma unroll
             for (int o = 0; o < OUT; o++) acc[o][k] += e[o] * hact;
         }
@@ -197,8 +210,12 @@ size_t skinny_backward_workspace(long rows, int hidden, int out_dim) {
     return (size_t)skinny_backward_blocks(rows, hidden) * out_dim * hidden * sizeof(float);
 }
 
+void to_split_words(const float* src, float* dst, size_t n) {
+    hipLaunchKernelGGL(split_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), src, dst, n);
+}
+
 void skinny_backward(const float* E, const float* Hpre, const float* W2, float* EH, float* dW2, long rows,
-                     int hidden, int out_dim, float* workspace, int accumulate) {
+                     int hidden, int out_dim, float* workspace, int accumulate, bool eh_split) {
     const int blocks = skinny_backward_blocks(rows, hidden);
     const int rpi = 256 / (hidden / 4);
     long rpb = (rows + blocks - 1) / blocks;
@@ -206,8 +223,12 @@ void skinny_backward(const float* E, const float* Hpre, const float* W2, float* 
     {
         ProfScope prof(K_SKINNY_BWD, (double)rows * (2.0 * hidden + out_dim) * 4.0);
 #define SKB(OUT)                                                                                              \
-    hipLaunchKernelGGL((skinny_backward_kernel<OUT>), dim3(blocks), dim3(256), 0, stream(), E, Hpre, W2, EH,  \
-                       workspace, rows, hidden, rpb)
+    if (eh_split)                                                                                             \
+        hipLaunchKernelGGL((skinny_backward_kernel<OUT, true>), dim3(blocks), dim3(256), 0, stream(), E, Hpre, W2, \
+                           EH, workspace, rows, hidden, rpb);                                                 \
+    else                                                                                                      \
+        hipLaunchKernelGGL((skinny_backward_kernel<OUT, false>), dim3(blocks), dim3(256), 0, stream(), E, Hpre, W2, \
+                           EH, workspace, rows, hidden, rpb)
         switch (out_dim) {
             case 1: SKB(1); break;
             case 2: SKB(2); break;
@@ -270,14 +291,19 @@ int mlp_gemm(const GemmArgs& g, int math) {
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T * Act[batch][cols]
 // Act rows are ld_act floats apart (ld_act >= cols; the trainer pads the 150-wide encoding to 160).
 void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, int ld_act, long batch, float* dW,
-                     float* workspace, int accumulate, int math) {
+                     float* workspace, int accumulate, int math, bool operands_split) {
     GemmArgs g = {};
+    g.operands_split = operands_split;
     g.A = Err; g.lda = rows_out; g.a_kc = 0;
     g.B = Act; g.ldb = ld_act; g.b_kc = 0;
     g.C = workspace; g.ldc = cols;
     g.M = rows_out; g.N = cols; g.K = (int)batch;
     g.epilogue = EPI_SPLITK;
     const bool split_math = math == MATH_SPLIT_BF16 && gemm_split_supported(g);
+    if (operands_split && !split_math) {
+        fprintf(stderr, "weight_gradient: split-word operands need the split-bf16 kernels\n");
+        exit(EXIT_FAILURE);
+    }
     const WgradPlan pl = split_math ? plan_weight_gradient_split(rows_out, cols, batch)
                                     : plan_weight_gradient(rows_out, cols, batch);
     const int splits = pl.splits;

@@ -31,8 +31,9 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
 int mlp_gemm(const GemmArgs& g, int math);
 bool skinny_ok(int hidden, int out_dim);
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]; workspace >= wgrad_slab_bytes(...)
+// operands_split: Err and Act hold split words (common.hpp); needs math == MATH_SPLIT_BF16
 void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, int ld_act, long batch, float* dW,
-                     float* workspace, int accumulate, int math);
+                     float* workspace, int accumulate, int math, bool operands_split = false);
 size_t wgrad_slab_bytes(int rows_out, int cols, long batch);
 
 }  // namespace nerf

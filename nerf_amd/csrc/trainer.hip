@@ -54,6 +54,10 @@ struct NerfTrainer {
     float* d_dwc;
     float* d_pair_tmp;
     float* d_pair_ws;
+    // split-bf16 + fused pair: the operands of the large products travel as split words
+    // (bf16 head << 16 | bf16 remainder, common.hpp): the encoding, both hidden activations' consumers'
+    // inputs, the two error matrices and the two weight matrices those products read
+    int words;
 };
 
 namespace {
@@ -96,6 +100,7 @@ PitchedInput encoded_input(NerfTrainer* tr) {
                                         (size_t)tr->pe_dim * 4, tr->cfg.hidden_dim, hipMemcpyDeviceToDevice,
                                         stream()));
         in.W1 = tr->d_w1p;
+        if (tr->words) to_split_words(tr->d_w1p, tr->d_w1p, (size_t)tr->cfg.hidden_dim * tr->pe_ld);
     }
     return in;
 }
@@ -164,6 +169,7 @@ int after_forward_fused(NerfTrainer* tr, int accumulate) {
         g.A = m2->d_W1; g.lda = M; g.a_kc = 1;
         g.B = m1->d_W2; g.ldb = H; g.b_kc = 0;
         g.C = tr->d_wc; g.ldc = H; g.M = H; g.N = H; g.K = M; g.epilogue = EPI_STORE;
+        g.c_split = tr->words;
         must(gemm_f32(g), "Wc = W1b W2a");
     }
     const PitchedInput in = encoded_input(tr);
@@ -174,6 +180,7 @@ int after_forward_fused(NerfTrainer* tr, int accumulate) {
         g.B = in.W1; g.ldb = in.ld; g.b_kc = 1;
         g.C = m1->d_layer_preact; g.C2 = m1->d_layer_postact; g.ldc = H;
         g.M = (int)N; g.N = H; g.K = in.ld; g.epilogue = EPI_SWISH;
+        g.operands_split = tr->words; g.c2_split = tr->words;
         must(mlp_gemm(g, math), "layer 1");
     }
     {
@@ -183,14 +190,16 @@ int after_forward_fused(NerfTrainer* tr, int accumulate) {
         g.B = tr->d_wc; g.ldb = H; g.b_kc = 1;
         g.C = m2->d_layer_preact; g.ldc = H;  // the output layer applies swish as it streams this in
         g.M = (int)N; g.N = H; g.K = H; g.epilogue = EPI_STORE;
+        g.operands_split = tr->words;
         must(mlp_gemm(g, math), "fused pair, forward");
     }
     skinny_forward(m2->d_layer_preact, m2->d_W2, m2->d_layer_output, N, H, O, true);
     const int rc = composite_and_gradient(tr, m2->d_layer_output, m2->d_error_output, accumulate);
     if (rc != NERF_OK) return rc;
     skinny_backward(m2->d_error_output, m2->d_layer_preact, m2->d_W2, m2->d_error_hidden, m2->d_W2_grad, N, H, O,
-                    m2->d_workspace, accumulate);
-    weight_gradient(m2->d_error_hidden, H, m1->d_layer_postact, H, H, N, tr->d_dwc, tr->d_pair_ws, 0, math);
+                    m2->d_workspace, accumulate, tr->words != 0);
+    weight_gradient(m2->d_error_hidden, H, m1->d_layer_postact, H, H, N, tr->d_dwc, tr->d_pair_ws, 0, math,
+                    tr->words != 0);
     {
         ProfScope prof(K_GEMM_WGRAD, 2.0 * small);
         GemmArgs g = {};  // dW1b [H][M] = dWc [H][H] * W2a[M][H]^T
@@ -213,10 +222,11 @@ int after_forward_fused(NerfTrainer* tr, int accumulate) {
         g.B = tr->d_wc; g.ldb = H; g.b_kc = 0;
         g.C = m1->d_error_hidden; g.AUX = m1->d_layer_preact; g.ldc = H;
         g.M = (int)N; g.N = H; g.K = H; g.epilogue = EPI_DSWISH_MUL;
+        g.operands_split = tr->words; g.c_split = tr->words;
         must(mlp_gemm(g, math), "fused pair, backward");
     }
     weight_gradient(m1->d_error_hidden, H, tr->d_pe, m1->input_dim, tr->pe_ld, N, m1->d_W1_grad, m1->d_workspace,
-                    accumulate, math);
+                    accumulate, math, tr->words != 0);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
@@ -293,9 +303,17 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
     dalloc(&tr->d_m, tr->n_params);
     dalloc(&tr->d_v, tr->n_params);
     tr->pe_ld = ((tr->pe_dim + 31) / 32) * 32;
+    // Split words need the large tile shapes of the split-bf16 kernels in all five big products.
+    // NERF_SPLIT_IN_REGISTERS=1 (a diagnostic switch) keeps fp32 operands and splits inside the kernels:
+    // bit-identical results, slower.
+    {
+        const char* env = getenv("NERF_SPLIT_IN_REGISTERS");
+        tr->words = cfg->precision == NERF_PRECISION_SPLIT_BF16 && cfg->fuse_linear_pair && !(env && env[0] == '1') &&
+                    H > 160 && H % 4 == 0 && N > 128 && (tr->pe_dim > 160 || wgrad_tile_n(tr->pe_dim) == 160);
+    }
     if (!bf16) {
         dalloc(&tr->d_pe, (size_t)N * tr->pe_ld);
-        if (tr->pe_ld != tr->pe_dim) dalloc(&tr->d_w1p, (size_t)H * tr->pe_ld);
+        if (tr->pe_ld != tr->pe_dim || tr->words) dalloc(&tr->d_w1p, (size_t)H * tr->pe_ld);
     }
     dalloc(&tr->d_target, (size_t)R * 3);
     dalloc(&tr->d_pixel, (size_t)R * 3);
@@ -412,6 +430,9 @@ static int forward_backward_impl(NerfTrainer* tr, const NerfDeviceDataset* datas
         if (tr->bf)
             rc = nerf_encode_batch_bf16(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane,
                                         c.far_plane, c.pos_enc_l, c.dir_enc_l, tr->bf->enc, tr->bf->pe_ld, tr->d_target);
+        else if (tr->words)
+            rc = nerf_encode_batch_split(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane,
+                                         c.far_plane, c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld, tr->d_target);
         else
             rc = nerf_encode_batch(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane, c.far_plane,
                                    c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld, tr->d_target, nullptr);
@@ -439,7 +460,8 @@ int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X
     int rc;
     {
         ProfScope prof(K_ENCODE, (double)N * tr->pe_dim * 4.0);
-        rc = nerf_encode_points(d_batch_X, N, c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld);
+        rc = tr->words ? nerf_encode_points_split(d_batch_X, N, c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld)
+                       : nerf_encode_points(d_batch_X, N, c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld);
     }
     if (rc != NERF_OK) return rc;
     if (hipMemcpyAsync(tr->d_target, d_target, (size_t)c.rays_per_batch * 3 * sizeof(float), hipMemcpyDeviceToDevice,

@@ -106,6 +106,45 @@ def test_three_steps_stay_with_the_plain_trainer(gpu, oracle_fast):
     assert np.abs(fused.tr.get_params() - plain.tr.get_params()).max() <= 0.05 * lr
 
 
+def test_split_words_are_bit_identical_to_splitting_in_the_kernels(gpu, oracle_fast, monkeypatch):
+    """With split-bf16 products AND the fused pair, the operands of the five large products travel as
+    split words (bf16 head << 16 | bf16 remainder) written by their producers; the kernels then only
+    unpack.  The split is the same function of the same fp32 value wherever it is taken, so results
+    must equal the in-kernel splitting bit for bit (NERF_SPLIT_IN_REGISTERS=1 selects that)."""
+    from nerf_amd.api import DeviceArray, Trainer
+    R, S = 64, 128
+    words = Pair(gpu, oracle_fast, R, S, precision=2, fuse_linear_pair=1)
+    monkeypatch.setenv("NERF_SPLIT_IN_REGISTERS", "1")
+    regs = Pair(gpu, oracle_fast, R, S, precision=2, fuse_linear_pair=1)
+    monkeypatch.delenv("NERF_SPLIT_IN_REGISTERS")
+    regs.tr.set_params(words.tr.get_params())
+    idx = words.indices(5)
+    d_idx = DeviceArray.from_numpy(idx)
+    for step in range(2):
+        words.tr.forward_backward(words.dds, d_idx)
+        regs.tr.forward_backward(regs.dds, d_idx)
+        gw, sw = words.tr.get_grads()
+        gr, sr = regs.tr.get_grads()
+        assert sw == sr and np.array_equal(gw, gr)
+        assert np.array_equal(words.tr.buffer(Trainer.BUF_RAW), regs.tr.buffer(Trainer.BUF_RAW))
+        words.tr.update(1e-4)
+        regs.tr.update(1e-4)
+    assert np.array_equal(words.tr.get_params(), regs.tr.get_params())
+    # the encoding buffer really holds split words in one and floats in the other
+    pw = words.tr.buffer(Trainer.BUF_PE).view(np.uint32)
+    pr = regs.tr.buffer(Trainer.BUF_PE)
+    head = (pw & 0xFFFF0000).view(np.float32).astype(np.float64)
+    rest = (pw << 16).view(np.float32).astype(np.float64)
+    assert not np.array_equal(pw.view(np.float32), pr)
+    np.testing.assert_allclose(head + rest, pr, rtol=2 ** -16, atol=1e-30)
+    # host-supplied samples take the same route
+    X = np.random.default_rng(3).uniform(-1, 1, (R * S, 6)).astype(np.float32)
+    tgt = np.random.default_rng(4).random((R, 3)).astype(np.float32)
+    for p in (words, regs):
+        p.tr.forward_backward_points(DeviceArray.from_numpy(X), DeviceArray.from_numpy(tgt))
+    assert np.array_equal(words.tr.get_grads()[0], regs.tr.get_grads()[0])
+
+
 def test_create_rejects_unsupported_combinations(gpu):
     from nerf_amd._lib import lib
     from nerf_amd.api import trainer_config
