@@ -242,7 +242,9 @@ float nerf_trainer_last_loss(NerfTrainer* tr);
 float nerf_trainer_learning_rate(const NerfTrainer* tr);
 int nerf_trainer_steps_done(const NerfTrainer* tr);
 /* device buffers of the last step, for checking: 0 encoding [N][pe], 1 raw output [N][out],
- * 2 pixel [R][3], 3 pixel error [R][3], 4 target [R][3], 5 dLoss/d(raw output) [N][out] */
+ * 2 pixel [R][3], 3 pixel error [R][3], 4 target [R][3], 5 dLoss/d(raw output) [N][out].
+ * With NERF_PRECISION_SPLIT_BF16 and fuse_linear_pair together, buffer 0 holds split words
+ * (nerf_encode_batch_split) instead of floats. */
 const float* nerf_trainer_buffer(NerfTrainer* tr, int which);
 /* Floats between consecutive rows of buffer 0 (the encoding): the encoding width rounded up to a
  * multiple of 32 (150 -> 160); the tail of every row is zero. */
