@@ -14,7 +14,40 @@
 
 using namespace nerf;
 
+namespace {
+
+// Staging buffers of the host-pointer functions below: grown on demand and kept, so that a training
+// loop calling them every step (train.c:176-178) does not pay a 315 MB hipMalloc/hipFree per call.
+// Released by nerf_host_api_release().
+struct Staging {
+    void* ptr;
+    size_t capacity;
+};
+Staging g_staging[3] = {};
+
+void* staging(int slot, size_t bytes) {
+    Staging& s = g_staging[slot];
+    if (s.capacity < bytes) {
+        if (s.ptr) NERF_HIP_CHECK(hipFree(s.ptr));
+        s.ptr = nullptr;
+        s.capacity = 0;
+        NERF_HIP_CHECK(hipMalloc(&s.ptr, bytes));
+        s.capacity = bytes;
+    }
+    return s.ptr;
+}
+
+}  // namespace
+
 extern "C" {
+
+void nerf_host_api_release(void) {
+    for (Staging& s : g_staging) {
+        if (s.ptr) (void)hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.capacity = 0;
+    }
+}
 
 void nerf_draw_ray_indices(const Dataset* dataset, int rays_per_batch, int* idx) {
     for (int ray = 0; ray < rays_per_batch; ray++) {
@@ -46,9 +79,8 @@ void batch_positional_encoding(const float* batch_X, int num_samples, int rays_p
                                int pos_enc_l, int dir_enc_l, int pe_input_dim) {
     const size_t n = (size_t)num_samples * rays_per_batch;
     if (n == 0) return;
-    float *d_x = nullptr, *d_pe = nullptr;
-    NERF_HIP_CHECK(hipMalloc((void**)&d_x, n * 6 * 4));
-    NERF_HIP_CHECK(hipMalloc((void**)&d_pe, n * pe_input_dim * 4));
+    float* d_x = (float*)staging(0, n * 6 * 4);
+    float* d_pe = (float*)staging(1, n * pe_input_dim * 4);
     NERF_HIP_CHECK(hipMemcpyAsync(d_x, batch_X, n * 6 * 4, hipMemcpyHostToDevice, stream()));
     if (nerf_encode_points(d_x, (int)n, pos_enc_l, dir_enc_l, d_pe, pe_input_dim) != NERF_OK) {
         fprintf(stderr, "batch_positional_encoding: bad arguments (pe_input_dim %d too small?)\n", pe_input_dim);
@@ -56,8 +88,6 @@ void batch_positional_encoding(const float* batch_X, int num_samples, int rays_p
     }
     NERF_HIP_CHECK(hipMemcpyAsync(batch_pe_X, d_pe, n * pe_input_dim * 4, hipMemcpyDeviceToHost, stream()));
     NERF_HIP_CHECK(hipStreamSynchronize(stream()));
-    hipFree(d_x);
-    hipFree(d_pe);
 }
 
 void generate_random_batch(const Dataset* dataset, int rays_per_batch, int num_samples, float near_plane,
@@ -79,12 +109,10 @@ void generate_random_batch(const Dataset* dataset, int rays_per_batch, int num_s
     }
     // rays and samples on the device (nerf.c:181-198)
     NerfDeviceDataset* cams = nerf_dataset_upload_cameras(dataset);
-    int* d_idx = nullptr;
-    float* d_x = nullptr;
     const size_t n = (size_t)rays_per_batch * num_samples;
     if (!cams) { fprintf(stderr, "generate_random_batch: device allocation failed\n"); exit(EXIT_FAILURE); }
-    NERF_HIP_CHECK(hipMalloc((void**)&d_idx, sizeof(int) * 3 * rays_per_batch));
-    NERF_HIP_CHECK(hipMalloc((void**)&d_x, n * 6 * 4));
+    int* d_idx = (int*)staging(2, sizeof(int) * 3 * rays_per_batch);
+    float* d_x = (float*)staging(0, n * 6 * 4);
     NERF_HIP_CHECK(hipMemcpyAsync(d_idx, idx, sizeof(int) * 3 * rays_per_batch, hipMemcpyHostToDevice, stream()));
     if (nerf_encode_batch(cams, d_idx, nullptr, rays_per_batch, num_samples, near_plane, far_plane, 0, 0, nullptr, 0,
                           nullptr, d_x) != NERF_OK) {
@@ -93,8 +121,6 @@ void generate_random_batch(const Dataset* dataset, int rays_per_batch, int num_s
     }
     NERF_HIP_CHECK(hipMemcpyAsync(batch_X, d_x, n * 6 * 4, hipMemcpyDeviceToHost, stream()));
     NERF_HIP_CHECK(hipStreamSynchronize(stream()));
-    hipFree(d_idx);
-    hipFree(d_x);
     nerf_dataset_release(cams);
     free(idx);
 }

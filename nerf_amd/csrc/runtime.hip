@@ -91,6 +91,16 @@ void nerf_device_free(void* p) {
     if (p) (void)hipFree(p);
 }
 
+void* nerf_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void nerf_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int nerf_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, nerf::g_stream) != hipSuccess) return NERF_ERR_HIP;
     return hipStreamSynchronize(nerf::g_stream) == hipSuccess ? NERF_OK : NERF_ERR_HIP;

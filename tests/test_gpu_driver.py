@@ -52,6 +52,8 @@ def test_classic_and_fused_paths_train_the_same_model(gpu, tmp_path):
     common = ["--data", str(tmp_path), "--images", "4", "--rays", "8", "--samples", "32", "--batches", "4",
               "--seed", "3", "--log-every", "2", "--render-every", "0"]
     out_c = run(common + ["--path", "classic", "--save", "c"], str(tmp_path))
+    out_p = run(common + ["--path", "classic", "--pin", "0", "--save", "p"], str(tmp_path))  # pageable host buffers, as train.c
+    assert [l for l in out_p.splitlines() if "Loss:" in l][-1].split("(")[0] == [l for l in out_c.splitlines() if "Loss:" in l][-1].split("(")[0]
     out_f = run(common + ["--path", "fused", "--save", "f"], str(tmp_path))
     assert "Batch [4/4]" in out_c and "Batch [4/4]" in out_f
     loss = lambda out: [float(l.split("Loss:")[1].split(",")[0]) for l in out.splitlines() if "Loss:" in l]
