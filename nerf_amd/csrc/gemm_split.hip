@@ -9,8 +9,11 @@
 // better) -- coarser than the exact kernels' 2^-24, finer than the 11 significant bits of the
 // tensor-core mode the reference asks of its BLAS (cublasSetMathMode(.., CUBLAS_TENSOR_OP_MATH),
 // reference train.c:86).  The bf16 matrix pipe runs 16x the fp32 pipe, so three products cost 3/16
-// of the exact kernels' matrix time; the splitting (3 vector instructions per operand value) and LDS
-// traffic become the bound instead.  Opt-in: nothing uses this unless asked (GemmArgs::math).
+// of the exact kernels' matrix time; the splitting (2.5 vector instructions per operand value) and LDS
+// traffic become the bound instead.  Opt-in: nothing calls gemm_split unless asked to (an MLP's
+// matrix_math, NERF_PRECISION_SPLIT_BF16).  Operands may also arrive already split, as "split words"
+// (GemmArgs::operands_split: bf16 head << 16 | bf16 remainder, written by the producing kernels); the
+// loop then only unpacks them, with bit-identical results.
 //
 // Tile shapes: 256x256 (eight wavefronts 2x4, 4x2 MFMA tiles each, one workgroup per CU) for the
 // large products, 128x128 (four wavefronts, two workgroups per CU) for small ones, and 128x160 for
