@@ -111,6 +111,33 @@ def test_encode_points_and_host_functions(gpu, oracle):
         np.testing.assert_allclose(o, ref, rtol=0, atol=TRIG_ATOL)
 
 
+def test_page_locked_buffers_and_kept_staging(gpu):
+    """nerf_host_alloc buffers (a drop-in for train.c:135-137's malloc) through the host-pointer
+    functions: same bytes as from pageable memory; the staging buffers survive growing, shrinking and
+    nerf_host_api_release between calls"""
+    from nerf_amd._lib import lib, c_float_p
+    import ctypes
+    rng = np.random.default_rng(2)
+    Lp, Ld, pe_dim = 16, 8, 150
+    for n in (64, 4000, 300):   # grow, then a smaller call in the kept buffers
+        X = np.concatenate([rng.uniform(-6, 6, (n, 3)), rng.normal(size=(n, 3))], axis=1).astype(np.float32)
+        want = np.empty((n, pe_dim), np.float32)
+        lib.batch_positional_encoding(X.ctypes.data_as(c_float_p), n, 1, want.ctypes.data_as(c_float_p), Lp, Ld, pe_dim)
+        hx, hpe = lib.nerf_host_alloc(X.nbytes), lib.nerf_host_alloc(want.nbytes)
+        assert hx and hpe
+        ctypes.memmove(hx, X.ctypes.data, X.nbytes)
+        lib.batch_positional_encoding(ctypes.cast(hx, c_float_p), n, 1, ctypes.cast(hpe, c_float_p), Lp, Ld, pe_dim)
+        got = np.ctypeslib.as_array(ctypes.cast(hpe, c_float_p), shape=(n, pe_dim)).copy()
+        assert np.array_equal(got, want)
+        lib.nerf_host_free(hx)
+        lib.nerf_host_free(hpe)
+        if n == 4000:
+            lib.nerf_host_api_release()   # the next call allocates afresh
+    lib.nerf_host_api_release()
+    lib.nerf_host_api_release()           # idempotent
+    lib.nerf_host_free(None)
+
+
 def test_generate_random_batch_draw_order(gpu, oracle, libc):
     """generate_random_batch draws image, u, v per ray with rand() in the reference's order
     (nerf.c:168-173): with the same srand() seed the oracle's draws and batch are identical."""
