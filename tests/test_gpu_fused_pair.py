@@ -152,3 +152,25 @@ def test_create_rejects_unsupported_combinations(gpu):
     for kw in (dict(fuse_linear_pair=1, precision=1), dict(fuse_linear_pair=2), dict(fuse_linear_pair=1, hidden_dim=24)):
         cfg = trainer_config(rays_per_batch=4, num_samples=8, **kw)
         assert not lib.nerf_trainer_create(C.byref(cfg), None, None)
+
+
+def test_trainers_release_their_device_memory(gpu):
+    """create/destroy in every mode: the device's free memory comes back (no leaked buffers)"""
+    import ctypes as C
+    import gc
+    torch = pytest.importorskip("torch")
+    from nerf_amd._lib import lib
+    from nerf_amd.api import Trainer, trainer_config
+    torch.cuda.init()
+    modes = [dict(), dict(precision=2), dict(fuse_linear_pair=1), dict(precision=2, fuse_linear_pair=1), dict(precision=1)]
+    Trainer(trainer_config(rays_per_batch=64, num_samples=128)).destroy()   # one-time runtime allocations first
+    lib.nerf_stream_synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for rep in range(2):
+        for kw in modes:
+            tr = Trainer(trainer_config(rays_per_batch=256, num_samples=128, **kw))
+            tr.destroy()
+    gc.collect()
+    lib.nerf_stream_synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 1024 * 1024, f"{(free0 - free1) / 2**20:.0f} MiB not returned"
