@@ -145,6 +145,9 @@ int nerf_encode_points_split(const float* d_batch_X, int num_points, int pos_enc
 int nerf_encode_view(const Camera* cam, int render_w, int render_h, int first_pixel, int num_pixels, int S,
                      float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe,
                      float* d_batch_X);
+/* the same, writing split words (see nerf_encode_batch_split) */
+int nerf_encode_view_split(const Camera* cam, int render_w, int render_h, int first_pixel, int num_pixels, int S,
+                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe);
 
 /* ---- compositing on the raw MLP output (activation fused) -------------------------------------- */
 /* activation_kernel + volume_rendering_and_loss_kernel without the loss (nerf.c:7-19,21-57) in one

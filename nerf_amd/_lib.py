@@ -132,6 +132,8 @@ _SIGS = {
                                           C.c_int, VP]),
     "nerf_encode_view": (C.c_int, [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                    C.c_float, C.c_int, C.c_int, VP, C.c_int, VP]),
+    "nerf_encode_view_split": (C.c_int, [C.POINTER(Camera), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                         C.c_float, C.c_int, C.c_int, VP, C.c_int]),
     # compositing
     "nerf_composite_forward": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP, VP, VP, C.c_int, C.c_int]),
     "nerf_loss_accumulate": (C.c_int, [VP, C.c_int, VP]),

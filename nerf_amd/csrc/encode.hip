@@ -378,4 +378,18 @@ int nerf_encode_view(const Camera* cam, int render_w, int render_h, int first_pi
     return launch_encode(a);
 }
 
+int nerf_encode_view_split(const Camera* cam, int render_w, int render_h, int first_pixel, int num_pixels, int S,
+                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe) {
+    if (!cam || !d_pe || render_w <= 0 || render_h <= 0 || first_pixel < 0 ||
+        (long long)first_pixel + num_pixels > (long long)render_w * render_h)
+        return NERF_ERR_ARG;
+    EncodeArgs a = {};
+    a.source = SRC_VIEW;
+    memcpy(&a.view, cam, sizeof(DeviceCamera));
+    a.render_w = render_w; a.render_h = render_h; a.first_pixel = first_pixel;
+    a.R = num_pixels; a.S = S; a.near_plane = near_plane; a.far_plane = far_plane;
+    a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = d_pe; a.pe_format = PE_SPLIT; a.ld_pe = ld_pe;
+    return launch_encode(a);
+}
+
 }  // extern "C"

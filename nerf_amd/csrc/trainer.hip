@@ -572,9 +572,14 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
     unsigned char* d_rgb8 = nullptr;
     int rc = NERF_OK;
     const int H1 = mlp1->hidden_dim, H2 = mlp2->hidden_dim, Mid = mlp1->output_dim;
+    // split-bf16 + fused pair: the two products read split words (see NerfTrainer::words); both fit
+    // the large tile shape when the widths and the chunk allow
+    const bool words = fuse_linear_pair && mlp1->matrix_math == MATH_SPLIT_BF16 && H1 > 160 && H2 > 160 &&
+                       H1 % 4 == 0 && H2 % 4 == 0 && N > 128 && !(getenv("NERF_SPLIT_IN_REGISTERS") &&
+                                                                 getenv("NERF_SPLIT_IN_REGISTERS")[0] == '1');
     if (!r1 || !r2 || hipMalloc((void**)&d_pe, (size_t)N * pe_ld * 4) != hipSuccess ||
         (fuse_linear_pair && hipMalloc((void**)&d_wc, (size_t)H2 * H1 * 4) != hipSuccess) ||
-        (pe_ld != pe_dim && hipMalloc((void**)&d_w1p, (size_t)mlp1->hidden_dim * pe_ld * 4) != hipSuccess) ||
+        ((pe_ld != pe_dim || words) && hipMalloc((void**)&d_w1p, (size_t)mlp1->hidden_dim * pe_ld * 4) != hipSuccess) ||
         hipMalloc((void**)&d_pixel, (size_t)total * 3 * 4) != hipSuccess ||
         hipMalloc((void**)&d_rgb8, (size_t)total * 3) != hipSuccess)
         rc = NERF_ERR_HIP;
@@ -586,12 +591,14 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
             NERF_HIP_CHECK(hipMemcpy2DAsync(d_w1p, (size_t)pe_ld * 4, mlp1->d_W1, (size_t)pe_dim * 4, (size_t)pe_dim * 4,
                                             mlp1->hidden_dim, hipMemcpyDeviceToDevice, stream()));
             in.W1 = d_w1p;
+            if (words) to_split_words(d_w1p, d_w1p, (size_t)mlp1->hidden_dim * pe_ld);
         }
         if (fuse_linear_pair) {  // Wc = W1b W2a, once per view (see after_forward_fused)
             GemmArgs g = {};
             g.A = mlp2->d_W1; g.lda = Mid; g.a_kc = 1;
             g.B = mlp1->d_W2; g.ldb = H1; g.b_kc = 0;
             g.C = d_wc; g.ldc = H1; g.M = H2; g.N = H1; g.K = Mid; g.epilogue = EPI_STORE;
+            g.c_split = words;
             rc = gemm_f32(g);
         }
     }
@@ -600,8 +607,10 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
         // a short last chunk still runs the MLPs at the full chunk size; the extra rows are ignored
         {
             ProfScope prof(K_ENCODE, (double)count * num_samples * pe_dim * 4.0);
-            rc = nerf_encode_view(cam, render_w, render_h, first, count, num_samples, near_plane, far_plane, pos_enc_l,
-                                  dir_enc_l, d_pe, pe_ld, nullptr);
+            rc = words ? nerf_encode_view_split(cam, render_w, render_h, first, count, num_samples, near_plane, far_plane,
+                                                pos_enc_l, dir_enc_l, d_pe, pe_ld)
+                       : nerf_encode_view(cam, render_w, render_h, first, count, num_samples, near_plane, far_plane,
+                                          pos_enc_l, dir_enc_l, d_pe, pe_ld, nullptr);
         }
         if (rc != NERF_OK) break;
         if (fuse_linear_pair) {
@@ -611,6 +620,7 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
                 g.A = in.X; g.lda = in.ld; g.a_kc = 1;
                 g.B = in.W1; g.ldb = in.ld; g.b_kc = 1;
                 g.C2 = r1->d_layer_postact; g.ldc = H1; g.M = N; g.N = H1; g.K = in.ld; g.epilogue = EPI_SWISH;
+                g.operands_split = words; g.c2_split = words;
                 must(mlp_gemm(g, r1->matrix_math), "render: layer 1");
             }
             {
@@ -619,6 +629,7 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
                 g.A = r1->d_layer_postact; g.lda = H1; g.a_kc = 1;
                 g.B = d_wc; g.ldb = H1; g.b_kc = 1;
                 g.C2 = r2->d_layer_postact; g.ldc = H2; g.M = N; g.N = H2; g.K = H1; g.epilogue = EPI_SWISH;
+                g.operands_split = words;
                 must(mlp_gemm(g, r1->matrix_math), "render: fused pair");
             }
             skinny_forward(r2->d_layer_postact, r2->d_W2, r2->d_layer_output, N, H2, r2->output_dim);

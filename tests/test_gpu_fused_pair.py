@@ -175,3 +175,24 @@ def test_trainers_release_their_device_memory(gpu):
     lib.nerf_stream_synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 * 1024 * 1024, f"{(free0 - free1) / 2**20:.0f} MiB not returned"
+
+
+def test_render_with_split_words_is_bit_identical(gpu, oracle_fast, monkeypatch):
+    """nerf_render_view_opts with split-bf16 MLPs and the fused pair reads split words as well; the
+    picture equals the one from splitting inside the kernels, and the exact-fp32 picture to the
+    product tolerance"""
+    from nerf_amd.api import make_camera
+    from conftest import make_scene
+    p = Pair(gpu, oracle_fast, 16, 128, precision=2, fuse_linear_pair=1)
+    q = Pair(gpu, oracle_fast, 16, 128)
+    q.tr.set_params(p.tr.get_params())
+    cams, _ = make_scene(1, 40, 30)
+    cam = make_camera(*cams[0])
+    rgb_w, pix_w = p.tr.render_view(cam, 24, 16, rays_per_chunk=96, fuse_linear_pair=True)
+    monkeypatch.setenv("NERF_SPLIT_IN_REGISTERS", "1")
+    rgb_r, pix_r = p.tr.render_view(cam, 24, 16, rays_per_chunk=96, fuse_linear_pair=True)
+    monkeypatch.delenv("NERF_SPLIT_IN_REGISTERS")
+    assert np.array_equal(pix_w, pix_r) and np.array_equal(rgb_w, rgb_r)
+    _, pix_e = q.tr.render_view(cam, 24, 16, rays_per_chunk=96)
+    np.testing.assert_allclose(pix_w, pix_e, rtol=0, atol=1e-4)
+    assert not np.array_equal(pix_w, pix_e)
