@@ -32,9 +32,9 @@ PEAK_HBM_GBS = 8000.0
 
 # logical product -> the kernel instance that carries it at the benchmark's shapes (rocprofv3 names)
 GEMM_KERNEL = {
-    "gemm_fwd": "gemm_dma_kernel<true, true, 2, 2, 2, 2>",
-    "gemm_dgrad": "gemm_dma_kernel<true, false, 2, 2, 2, 2>",
-    "gemm_wgrad": "gemm_dma_kernel<false, false, 2, 2, 2, 2>",
+    "gemm_fwd": "gemm_dma_kernel<true, true, 2, 2, 2, 2, 16>",
+    "gemm_dgrad": "gemm_dma_kernel<true, false, 2, 2, 2, 2, 16>",
+    "gemm_wgrad": "gemm_dma_kernel<false, false, 2, 2, 2, 2, 32>",
 }
 SPLIT_KERNEL = {
     "gemm_fwd": "gemm_split_kernel<true, true, 2, 4, 4, 2>",
@@ -165,7 +165,7 @@ def render_workload(args, lib, torch):
                                f"{args.rays} rays, MLP 150-512-512-512-4, fp32"
                                + (", split-bf16 products (opt-in)" if split else "")
                                + (", linear pair fused (opt-in)" if fused else "")},
-        "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<true, true, 2, 2, 2, 2> (forward products)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<true, true, 2, 2, 2, 2, 16> (forward products)",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                      "gemm_share_of_step": ms / (el * 1e3)},
@@ -386,7 +386,8 @@ def main():
         names = (SPLIT_WORDS_KERNEL if fused else SPLIT_KERNEL) if split else GEMM_KERNEL
         traffic, mfma_util = pmc_traffic(names[dom],
                                           ("fused_" if fused else "") + ("split_" if split else ""))
-        kernel_label = f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x32 tiles, LDS-DMA staged)"
+        ksteps = 32 if dom == "gemm_wgrad" else 16
+        kernel_label = f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x{ksteps} tiles, LDS-DMA staged)"
         peak = PEAK_F32_MFMA_TFLOPS
         if split:
             # three bf16 products are executed per algorithmic product: price the executed work

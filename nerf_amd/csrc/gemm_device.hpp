@@ -72,9 +72,9 @@ __device__ __forceinline__ void decode_block(const KernelArgs& ka, int b, int& t
 // applied to the SOURCE address.  KC tiles are [ROWS][8 chunks of 16 B] with chunk c of row r
 // stored at position c ^ ((r >> 1) & 7): the 16 rows a ds_read_b128 lane group touches then fall on
 // 16 different bank slots without padding.  KS tiles ([32][ROWS]) need no swizzle.
-template <bool KC, int ROWS, int NT = 256>
+template <bool KC, int ROWS, int NT = 256, int BKT = BK>
 struct DmaLoader {
-    static constexpr int SLOTS = ROWS * BK / 4;  // 16-byte pieces per tile
+    static constexpr int SLOTS = ROWS * BKT / 4;  // 16-byte pieces per tile
     static constexpr int PASSES = SLOTS / NT;    // NT = threads of the workgroup
     static_assert(SLOTS % NT == 0, "tile must split evenly over the workgroup's lanes");
     __amdgpu_buffer_rsrc_t rsrc;
@@ -86,17 +86,20 @@ struct DmaLoader {
         if (KC) {                 // element (row, k) at row*ld + k
             first = (size_t)x0 * ld + kbeg;
             remaining = (size_t)(X - x0 - 1) * ld + (K - kbeg);
-            tile_stride = BK * 4u;
+            tile_stride = BKT * 4u;
         } else {                  // element (k, x) at k*ld + x
             first = (size_t)kbeg * ld + x0;
             remaining = (size_t)(K - kbeg - 1) * ld + (X - x0);
-            tile_stride = (unsigned)(BK * ld) * 4u;
+            tile_stride = (unsigned)(BKT * ld) * 4u;
         }
 #pragma unroll
         for (int p = 0; p < PASSES; p++) {
             const int L = p * NT + tid;  // slot of the LDS image this lane fills in pass p
-            if (KC) {
+            if (KC && BKT == 32) {
                 const int row = L >> 3, c = (L & 7) ^ ((row >> 1) & 7);
+                voff[p] = (unsigned)(row * ld + c * 4) * 4u;
+            } else if (KC) {  // 16-step tiles: rows of 64 bytes, 4 chunks, swizzled by (row >> 2) & 3
+                const int row = L >> 2, c = (L & 3) ^ ((row >> 2) & 3);
                 voff[p] = (unsigned)(row * ld + c * 4) * 4u;
             } else {
                 const int krow = L / (ROWS / 4), xq = (L % (ROWS / 4)) * 4;
@@ -118,12 +121,12 @@ struct DmaLoader {
 };
 // One 8-step group of an operand tile staged by DmaLoader, as the 32x32 MFMAs want it:
 // frag[j]: lane l holds element (row rb + (l & 31), k = 8kk + 4(l >> 5) + j)
-template <bool KC, int ROWS>
+template <bool KC, int ROWS, int BKT = BK>
 __device__ __forceinline__ void dma_frag(float (&frag)[4], const float* __restrict__ T, int rb, int kk, int lane) {
     if (KC) {
         const int row = rb + (lane & 31);
-        const int chunk = (kk * 2 + (lane >> 5)) ^ ((row >> 1) & 7);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * BK + chunk * 4);
+        const int chunk = BKT == 32 ? (kk * 2 + (lane >> 5)) ^ ((row >> 1) & 7) : (kk * 2 + (lane >> 5)) ^ ((row >> 2) & 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(T + row * BKT + chunk * 4);
         frag[0] = v[0]; frag[1] = v[1]; frag[2] = v[2]; frag[3] = v[3];
     } else {
         const float* src = T + (kk * 8 + 4 * (lane >> 5)) * ROWS + rb + (lane & 31);

@@ -4,15 +4,20 @@
 // inside forward_pass_mlp / backward_pass_mlp (call sites reference train.c:188-189,215-216).
 //
 // A 256-thread workgroup (4 wavefronts) computes one output tile; a wavefront owns MI x NI MFMA
-// tiles of 32x32 (16 accumulator registers each).  Operand tiles of 32 contraction steps are double
-// buffered in LDS, one barrier per K-tile.  Two kernels:
+// tiles of 32x32 (16 accumulator registers each).  Operand tiles of 32 or 16 contraction steps are
+// double buffered in LDS, one barrier per K-tile.  Two kernels:
 //
-//   gemm_dma_kernel      the fast path (16-byte aligned operands, K a multiple of 32).  Operand tiles
+//   gemm_dma_kernel      the fast path (16-byte aligned operands, K a multiple of the K-tile).  Operand tiles
 //                        go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
 //                        registers, no ds_write, the DMA of tile t+1 is issued at the top of tile t
 //                        and waited for just before the barrier.  Tile shapes 128x128 (waves 2x2,
 //                        2x2 MFMA tiles each) and 128x160 (waves 4x1, 1x5 MFMA tiles each; for the
 //                        150-column weight gradient, which a 128-wide tiling would pad to 256).
+//                        Products with a row-major A (forward layers, data gradients) use
+//                        16-step K-tiles: 32 KB of LDS and < 128 registers let four workgroups
+//                        share a CU, and their stores then hide behind the others' MFMAs
+//                        (measured 2.19 -> 2.06 ms with the swish epilogue); the split-K weight
+//                        gradient stores almost nothing and keeps 32-step tiles (fewer barriers).
 //   gemm_generic_kernel  anything else (8- or 4-byte aligned rows such as dense 150-float rows,
 //                        ragged K): global -> registers -> LDS with guarded buffer loads.
 //
@@ -41,30 +46,31 @@ constexpr int KC_LD = BK + 4;  // generic kernel: floats per LDS row of a KC til
 // ================================================================================================
 // Fast path: LDS-DMA operand staging (DmaLoader: gemm_device.hpp)
 // ================================================================================================
-// One K-tile: start the DMA of tile `next` into the other buffer, run the 32 contraction steps of
+// One K-tile: start the DMA of tile `next` into the other buffer, run the BKT contraction steps of
 // buffer CUR, barrier.  (`next` past the end re-fetches the last tile; it is never read.)
-template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int CUR>
-__device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 * BK], const DmaLoader<A_KC, WM * MI * 32>& da,
-                                       const DmaLoader<B_KC, WN * NI * 32>& db, f32x16 (&acc)[MI][NI], int next,
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int CUR, int BKT>
+__device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 * BKT],
+                                       const DmaLoader<A_KC, WM * MI * 32, 256, BKT>& da,
+                                       const DmaLoader<B_KC, WN * NI * 32, 256, BKT>& db, f32x16 (&acc)[MI][NI], int next,
                                        int wave, int wm, int wn, int lane) {
-    constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32, A_TILE = BM_ * BK;
+    constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32, A_TILE = BM_ * BKT;
     da.issue(lds[CUR ^ 1], next, wave);
     db.issue(lds[CUR ^ 1] + A_TILE, next, wave);
     const float* TA = lds[CUR];
     const float* TB = lds[CUR] + A_TILE;
     float fa[2][MI][4], fb[2][NI][4];
 #pragma unroll
-    for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_>(fa[0][i], TA, wm * MI * 32 + i * 32, 0, lane);
+    for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_, BKT>(fa[0][i], TA, wm * MI * 32 + i * 32, 0, lane);
 #pragma unroll
-    for (int i = 0; i < NI; i++) dma_frag<B_KC, BN_>(fb[0][i], TB, wn * NI * 32 + i * 32, 0, lane);
+    for (int i = 0; i < NI; i++) dma_frag<B_KC, BN_, BKT>(fb[0][i], TB, wn * NI * 32 + i * 32, 0, lane);
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; kk++) {
+    for (int kk = 0; kk < BKT / 8; kk++) {
         const int c = kk & 1, n = c ^ 1;
-        if (kk + 1 < BK / 8) {
+        if (kk + 1 < BKT / 8) {
 #pragma unroll
-            for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_>(fa[n][i], TA, wm * MI * 32 + i * 32, kk + 1, lane);
+            for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_, BKT>(fa[n][i], TA, wm * MI * 32 + i * 32, kk + 1, lane);
 #pragma unroll
-            for (int i = 0; i < NI; i++) dma_frag<B_KC, BN_>(fb[n][i], TB, wn * NI * 32 + i * 32, kk + 1, lane);
+            for (int i = 0; i < NI; i++) dma_frag<B_KC, BN_, BKT>(fb[n][i], TB, wn * NI * 32 + i * 32, kk + 1, lane);
         }
         // keep the reads of group kk+1 in front of group kk's MFMAs: left alone, the scheduler
         // sinks each read to just before its use and the MFMAs wait out a full LDS latency
@@ -80,10 +86,10 @@ __device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 
     __syncthreads();
 }
 
-template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI>
-__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const KernelArgs ka) {
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int BKT = BK>
+__global__ __launch_bounds__(256, BKT == 32 ? 2 : 3) void gemm_dma_kernel(const KernelArgs ka) {
     constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32;
-    constexpr int A_TILE = BM_ * BK, B_TILE = BN_ * BK;
+    constexpr int A_TILE = BM_ * BKT, B_TILE = BN_ * BKT;
     static_assert(WM * WN == 4 && BM_ == 128, "four wavefronts, 128-row tiles");
     __shared__ __attribute__((aligned(16))) float lds[2][A_TILE + B_TILE];
     const GemmArgs& p = ka.g;
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const KernelArgs ka) {
         kbeg = split * p.k_chunk;
         kend = min(p.K, kbeg + p.k_chunk);
     }
-    const int nkt = kend > kbeg ? (kend - kbeg) / BK : 0;  // whole tiles only (checked by the host)
+    const int nkt = kend > kbeg ? (kend - kbeg) / BKT : 0;  // whole tiles only (checked by the host)
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -112,8 +118,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const KernelArgs ka) {
     // that ended tile kt-1) and has the whole tile to land; __syncthreads() waits for it (vmcnt)
     // before the barrier.  The loop is unrolled by two so that the buffer index is a compile-time
     // constant: every LDS address is then a loop-invariant per-lane register plus an immediate.
-    const DmaLoader<A_KC, BM_> da(p.A, p.lda, m0, p.M, p.K, kbeg, tid);
-    const DmaLoader<B_KC, BN_> db(p.B, p.ldb, n0, p.N, p.K, kbeg, tid);
+    const DmaLoader<A_KC, BM_, 256, BKT> da(p.A, p.lda, m0, p.M, p.K, kbeg, tid);
+    const DmaLoader<B_KC, BN_, 256, BKT> db(p.B, p.ldb, n0, p.N, p.K, kbeg, tid);
     if (nkt > 0) {
         da.issue(lds[0], 0, wave);
         db.issue(lds[0] + A_TILE, 0, wave);
@@ -121,18 +127,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const KernelArgs ka) {
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nkt; kt += 2) {
-        k_tile<A_KC, B_KC, WM, WN, MI, NI, 0>(lds, da, db, acc, kt + 1, wave, wm, wn, lane);
-        k_tile<A_KC, B_KC, WM, WN, MI, NI, 1>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, wm, wn, lane);
+        k_tile<A_KC, B_KC, WM, WN, MI, NI, 0, BKT>(lds, da, db, acc, kt + 1, wave, wm, wn, lane);
+        k_tile<A_KC, B_KC, WM, WN, MI, NI, 1, BKT>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, wm, wn, lane);
     }
-    if (kt < nkt) k_tile<A_KC, B_KC, WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, wm, wn, lane);
+    if (kt < nkt) k_tile<A_KC, B_KC, WM, WN, MI, NI, 0, BKT>(lds, da, db, acc, kt, wave, wm, wn, lane);
     epilogue<MI, NI>(p, acc, m0, n0, split, wm * MI * 32, wn * NI * 32, lane);
 }
 
 // explicit instantiations (hipcc 7.2 drops the host stubs of some implicitly instantiated variants)
-template __global__ void gemm_dma_kernel<true, true, 2, 2, 2, 2>(const KernelArgs);
-template __global__ void gemm_dma_kernel<true, false, 2, 2, 2, 2>(const KernelArgs);
 template __global__ void gemm_dma_kernel<false, false, 2, 2, 2, 2>(const KernelArgs);
 template __global__ void gemm_dma_kernel<false, false, 4, 1, 1, 5>(const KernelArgs);
+template __global__ void gemm_dma_kernel<true, true, 2, 2, 2, 2, 16>(const KernelArgs);
+template __global__ void gemm_dma_kernel<true, false, 2, 2, 2, 2, 16>(const KernelArgs);
 
 // ================================================================================================
 // Generic path: guarded buffer loads -> registers -> LDS, 128x128 tiles
@@ -359,6 +365,10 @@ template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI>
 void launch_dma(const KernelArgs& ka, int grid) {
     hipLaunchKernelGGL((gemm_dma_kernel<A_KC, B_KC, WM, WN, MI, NI>), dim3(grid), dim3(256), 0, stream(), ka);
 }
+template <bool A_KC, bool B_KC>
+void launch_dma16(const KernelArgs& ka, int grid) {
+    hipLaunchKernelGGL((gemm_dma_kernel<A_KC, B_KC, 2, 2, 2, 2, 16>), dim3(grid), dim3(256), 0, stream(), ka);
+}
 
 // does an operand meet the DMA path's needs: 16-byte aligned base and rows; for KS also a row count
 // that keeps 16-byte pieces inside the matrix (x advances in fours: X may be ragged only if the
@@ -400,7 +410,7 @@ int gemm_f32(const GemmArgs& g) {
     if (g.epilogue == EPI_SPLITK && (g.splits <= 0 || g.k_chunk <= 0 || g.k_chunk % BK != 0)) return NERF_ERR_ARG;
     KernelArgs ka;
     ka.g = g;
-    const bool dma = g.K % BK == 0 && dma_operand_ok(g.A, g.lda, g.a_kc, g.M, g.K) &&
+    const bool dma = g.K % (g.a_kc ? 16 : BK) == 0 && dma_operand_ok(g.A, g.lda, g.a_kc, g.M, g.K) &&
                      dma_operand_ok(g.B, g.ldb, g.b_kc, g.N, g.K);
     // the 160-wide tile exists for the split-K weight gradient (both operands strided)
     const bool wide = dma && g.epilogue == EPI_SPLITK && !g.a_kc && !g.b_kc && g.tile_n == 160;
@@ -411,9 +421,12 @@ int gemm_f32(const GemmArgs& g) {
     if (grid > 0x7fffffffL) return NERF_ERR_ARG;
     const int gi = (int)grid;
     if (dma) {
+        // 16-step K-tiles (32 KB of LDS, four workgroups per CU) for the products that store a
+        // point-major result: more co-resident workgroups hide the epilogue's stores.  The
+        // weight gradient (both operands strided, slab epilogue) is faster on 32-step tiles.
         if (wide) launch_dma<false, false, 4, 1, 1, 5>(ka, gi);
-        else if (g.a_kc && g.b_kc) launch_dma<true, true, 2, 2, 2, 2>(ka, gi);
-        else if (g.a_kc) launch_dma<true, false, 2, 2, 2, 2>(ka, gi);
+        else if (g.a_kc && g.b_kc) launch_dma16<true, true>(ka, gi);
+        else if (g.a_kc) launch_dma16<true, false>(ka, gi);
         else launch_dma<false, false, 2, 2, 2, 2>(ka, gi);
     } else {
         const int va = operand_vec(g.A, g.lda, g.a_kc ? g.K : g.M);

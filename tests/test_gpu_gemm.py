@@ -36,6 +36,9 @@ CASES = [
     (200, 512, 160, 1, 1),     # DMA path, ragged rows
     (200, 150, 512, 1, 0),     # dense 150-wide output rows (ldc not a multiple of 4)
     (77, 384, 64, 1, 0),
+    (300, 256, 16, 1, 1),      # a single 16-step K-tile on the DMA path
+    (300, 256, 48, 1, 0),      # odd number of 16-step K-tiles (the loop is unrolled by two)
+    (257, 130, 144, 1, 1),     # K a multiple of 16 but not of 32, ragged rows and columns
 ]
 
 
