@@ -10,18 +10,16 @@
 //   cudaMemcpy H2D               train.c:182-185
 // and the per-pixel ray set-up of render_test_image (nerf.c:259-277).
 //
-// Work item = (point, slot).  A point's 150-float row is cut into 74 slots: slot 0 writes the
-// position itself, slots 1..48 one (sin, cos) pair of the position block (octave l, coordinate i),
-// slot 49 the direction itself, slots 50..73 one pair of the direction block.  Consecutive threads
-// write consecutive addresses, so the [points][150] matrix is produced with coalesced stores
-// (600 B per point: this kernel is HBM-write bound).
+// A workgroup encodes 64 consecutive points: samples are built once, every coordinate gets ONE
+// accurate sin/cos (double) and then a double-angle step per octave, the rows are assembled in LDS
+// and leave as full-line stores (600 B per point: this kernel is HBM-write bound).
 //
 // Bit-exactness: every IEEE operation of the ray set-up is done in the reference's order with
 // FMA contraction switched off (the __f*_rn intrinsics only spell the order out; the correctly
 // rounded sqrtf and '/' are hipcc's defaults), so sample positions and the float
 // arguments of sinf/cosf are bit-identical to a strict C evaluation.  The argument is formed as
 // (float)((double)2^l * M_PI * (double)x), which is what `freq * M_PI * input[i]` means in C
-// (nerf.c:141).  sinf/cosf are the full-range-reduction device functions.
+// (nerf.c:141).  sinf/cosf of it: sincos_reduced below (full-range reduction in double).
 #include "common.hpp"
 
 #include <string.h>
@@ -111,18 +109,95 @@ __device__ __forceinline__ void put(float* base, size_t index, float v) {
     }
 }
 
-// A workgroup owns ENC_POINTS consecutive points.  Phase 1: one thread per point builds the sample
-// (ray through the pixel, depth, position) once and parks position and direction in LDS.  Phase 2:
-// the 256 threads walk the (point, slot) items of those points -- slot = one identity triple or one
-// (octave, coordinate) sin/cos pair -- so that a wavefront's stores run along an encoding row.
+// sin and cos of a float argument below 1.6e6 in magnitude (octave 15 of a coordinate of +-10 is
+// 1.03e6), as doubles.  The argument is reduced in double -- k = rint(arg * 2/pi),
+// r = arg - k * pi/2 with pi/2 as a 33-bit head (k * head is exact for |k| < 2^20) plus tail -- and
+// both polynomials (the classic degree-13 / degree-14 kernels on [-pi/4, pi/4]) run in double:
+// error below 1e-11 + 2^-53 |arg|, so the value rounded to float is at least as close to the C
+// library's sinf/cosf as the library's own 1-ulp bound.  Double FMAs run at the fp32 rate on this
+// chip; the general-purpose sincosf (float-only multi-word reduction) is several times longer.
+__device__ __forceinline__ void sincos_reduced_d(float arg, double& s, double& c) {
+    const double a = (double)arg;
+    const double kd = rint(__dmul_rn(a, 0.63661977236758134308));
+    double r = fma(-kd, 1.57079632673412561417e+00, a);
+    r = fma(-kd, 6.07710050650619224932e-11, r);
+    const double z = __dmul_rn(r, r);
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = fma(__dmul_rn(z, r), ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cs = fma(__dmul_rn(z, z), pc, fma(z, -0.5, 1.0));
+    const int q = (int)kd;
+    const double so = (q & 1) ? cs : sn, co = (q & 1) ? sn : cs;
+    s = (q & 2) ? -so : so;
+    c = ((q + 1) & 2) ? -co : co;
+}
+
+// sinf/cosf of any float argument
+__device__ __forceinline__ void sincos_reduced(float arg, float& s, float& c) {
+    if (!(fabsf(arg) < 1.6e6f)) {  // beyond the exact-head range, inf, nan
+        sincosf(arg, &s, &c);
+        return;
+    }
+    double sd, cd;
+    sincos_reduced_d(arg, sd, cd);
+    s = (float)sd;
+    c = (float)cd;
+}
+
+// All L octaves of one coordinate x: dst[6l] = sinf(arg_l), dst[6l + 1] = cosf(arg_l) with
+// arg_l = (float)((double)2^l * M_PI * (double)x) (nerf.c:139-142).  Scaling by a power of two
+// commutes with both roundings, so arg_l = 2^l * arg_0 exactly (outside the subnormal range, where
+// sin(arg) = arg and cos(arg) = 1 to far below float resolution either way): one accurate sin/cos
+// of arg_0 in double, then the double-angle step per octave.  A step doubles the absolute error
+// and adds a rounding: measured on the CPU over 96 M values, at most 7.3e-12 at the reference's 16
+// octaves (|x| <= 10), so below 1e-9 up to l = 20 with |arg_0| <= 64 -- invisible after rounding
+// to float.  Anything outside that range takes one reduction per octave.
+__device__ __forceinline__ void encode_coordinate(float x, int L, float* dst) {
+    const float arg0 = (float)__dmul_rn(3.14159265358979323846, (double)x);
+    if (L <= 20 && fabsf(arg0) <= 64.0f) {
+        double s, c;
+        sincos_reduced_d(arg0, s, c);
+        for (int l = 0; l < L; l++) {
+            dst[6 * l] = (float)s;
+            dst[6 * l + 1] = (float)c;
+            const double s2 = __dmul_rn(__dmul_rn(2.0, s), c);
+            c = __dmul_rn(__dsub_rn(c, s), __dadd_rn(c, s));  // keeps s^2 + c^2 - 1 from growing faster than the angle error
+            s = s2;
+        }
+    } else {
+        for (int l = 0; l < L; l++) {
+            const double freq = (double)(1u << l);  // powf(2, l) is exact for these l
+            const float arg = (float)(__dmul_rn(__dmul_rn(freq, 3.14159265358979323846), (double)x));
+            sincos_reduced(arg, dst[6 * l], dst[6 * l + 1]);
+        }
+    }
+}
+
+// A workgroup owns `P` (64, or 32 for very long rows) consecutive points.
+// Phase 1: one thread per point builds the sample (ray through the pixel, depth, position) once and
+//          parks position and direction in LDS.
+// Phase 2: one thread per (coordinate, point) writes that coordinate's identity column and all its
+//          octaves into an LDS image of the encoding rows.  Rows have an odd stride, so a
+//          wavefront -- 64 points, same column -- writes 64 different banks.
+// Phase 3: each wavefront copies whole rows to memory, a lane per consecutive float: every store
+//          instruction covers 256 contiguous bytes whatever the row pitch.
 constexpr int ENC_POINTS = 64;
 
 template <int BF16>
-__global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a) {
+__global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a, const int P, const int row_ld) {
     __shared__ float sample[ENC_POINTS][6];
+    extern __shared__ float rows[];  // [P][row_ld]
     const long long n_points = (long long)a.R * a.S;
-    const long long p0 = (long long)blockIdx.x * ENC_POINTS;
-    if (threadIdx.x < ENC_POINTS && p0 + threadIdx.x < n_points) {
+    const long long p0 = (long long)blockIdx.x * P;
+    if (threadIdx.x < P && p0 + threadIdx.x < n_points) {
         const long long point = p0 + threadIdx.x;
         const int ray = (int)(point / a.S), s = (int)(point - (long long)ray * a.S);
         float pos[3], dir[3];
@@ -169,32 +244,27 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a) {
     if (!a.pe) return;
     __syncthreads();
 
-    const int pos_w = NERF_PE_DIM3(a.pos_l);
-    const int slots_pos = 1 + 3 * a.pos_l, slots = slots_pos + 1 + 3 * a.dir_l;
+    const int pos_w = NERF_PE_DIM3(a.pos_l), pe_dim = pos_w + NERF_PE_DIM3(a.dir_l);
     const long long left = n_points - p0;
-    const int here = left < ENC_POINTS ? (int)left : ENC_POINTS;
-    for (int item = threadIdx.x; item < here * slots; item += 256) {
-        const int pt = item / slots, slot = item - pt * slots;
-        const float* v = sample[pt];
-        const size_t row = (size_t)(p0 + pt) * a.ld_pe;
-        if (slot == 0) {
-            put<BF16>(a.pe, row + 0, v[0]); put<BF16>(a.pe, row + 1, v[1]); put<BF16>(a.pe, row + 2, v[2]);
-        } else if (slot == slots_pos) {
-            put<BF16>(a.pe, row + pos_w + 0, v[3]); put<BF16>(a.pe, row + pos_w + 1, v[4]);
-            put<BF16>(a.pe, row + pos_w + 2, v[5]);
-        } else {
-            const bool is_dir = slot > slots_pos;
-            const int k = is_dir ? slot - slots_pos - 1 : slot - 1;
-            const int l = k / 3, i = k - 3 * l;
-            const float x = v[(is_dir ? 3 : 0) + i];
-            const double freq = (double)(1u << l);  // powf(2, l) is exact for these l
-            const float arg = (float)(__dmul_rn(__dmul_rn(freq, 3.14159265358979323846), (double)x));
-            float sv, cv;
-            sincosf(arg, &sv, &cv);
-            const size_t dst = row + (is_dir ? pos_w : 0) + 3 + 6 * l + 2 * i;
-            put<BF16>(a.pe, dst, sv);
-            put<BF16>(a.pe, dst + 1, cv);
-        }
+    const int here = left < P ? (int)left : P;
+    const int shift = P == 64 ? 6 : 5;
+    for (int item = threadIdx.x; item < 6 * P; item += 256) {
+        const int c = item >> shift, pt = item & (P - 1);  // coordinate 0-2 position, 3-5 direction
+        if (pt >= here) continue;
+        const bool is_dir = c >= 3;
+        const int i = is_dir ? c - 3 : c;
+        const float x = sample[pt][c];
+        float* row = rows + pt * row_ld + (is_dir ? pos_w : 0);
+        row[i] = x;
+        encode_coordinate(x, is_dir ? a.dir_l : a.pos_l, row + 3 + 2 * i);
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int pt = wave; pt < here; pt += 4) {
+        const float* src = rows + pt * row_ld;
+        const size_t dst = (size_t)(p0 + pt) * a.ld_pe;
+        for (int col = lane; col < pe_dim; col += 64) put<BF16>(a.pe, dst + col, src[col]);
     }
 }
 
@@ -208,7 +278,7 @@ __global__ __launch_bounds__(256) void pe_vector_kernel(const float* __restrict_
     const double freq = ldexp(1.0, l);
     const float arg = (float)(__dmul_rn(__dmul_rn(freq, 3.14159265358979323846), (double)in[i]));
     float sv, cv;
-    sincosf(arg, &sv, &cv);
+    sincos_reduced(arg, sv, cv);
     out[dim + 2 * dim * l + 2 * i + 0] = sv;
     out[dim + 2 * dim * l + 2 * i + 1] = cv;
 }
@@ -218,14 +288,18 @@ int launch_encode(const EncodeArgs& a) {
         a.pos_l > 30 || a.dir_l > 30 || (!a.pe && !a.batch_X_out))
         return NERF_ERR_ARG;
     if (a.pe && a.ld_pe < NERF_PE_DIM3(a.pos_l) + NERF_PE_DIM3(a.dir_l)) return NERF_ERR_ARG;
-    const long long grid = ((long long)a.R * a.S + ENC_POINTS - 1) / ENC_POINTS;
+    // LDS image of the rows: odd stride, at most 60 KB (rows of up to 366 floats: 64 or 32 points)
+    const int row_ld = (NERF_PE_DIM3(a.pos_l) + NERF_PE_DIM3(a.dir_l)) | 1;
+    const int P = (size_t)ENC_POINTS * row_ld * 4 <= 60 * 1024 ? ENC_POINTS : ENC_POINTS / 2;
+    const size_t lds = a.pe ? (size_t)P * row_ld * 4 : 0;
+    const long long grid = ((long long)a.R * a.S + P - 1) / P;
     if (grid > 0x7fffffffLL) return NERF_ERR_ARG;
     if (a.pe_format == PE_BF16)
-        hipLaunchKernelGGL(encode_kernel<PE_BF16>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
+        hipLaunchKernelGGL(encode_kernel<PE_BF16>, dim3((unsigned)grid), dim3(256), lds, stream(), a, P, row_ld);
     else if (a.pe_format == PE_SPLIT)
-        hipLaunchKernelGGL(encode_kernel<PE_SPLIT>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
+        hipLaunchKernelGGL(encode_kernel<PE_SPLIT>, dim3((unsigned)grid), dim3(256), lds, stream(), a, P, row_ld);
     else
-        hipLaunchKernelGGL(encode_kernel<PE_F32>, dim3((unsigned)grid), dim3(256), 0, stream(), a);
+        hipLaunchKernelGGL(encode_kernel<PE_F32>, dim3((unsigned)grid), dim3(256), lds, stream(), a, P, row_ld);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 

@@ -111,6 +111,27 @@ def test_encode_points_and_host_functions(gpu, oracle):
         np.testing.assert_allclose(o, ref, rtol=0, atol=TRIG_ATOL)
 
 
+def test_encode_points_outside_the_recurrence_range(gpu, oracle):
+    """coordinates whose first-octave argument exceeds 64 and encodings of more than 20 octaves
+    leave the double-angle recurrence for one range reduction per octave (arguments up to 1e9)"""
+    from nerf_amd.api import DeviceArray
+    from nerf_amd._lib import lib
+    rng = np.random.default_rng(77)
+    n = 130
+    X = np.concatenate([rng.uniform(-900, 900, (n, 3)), rng.normal(size=(n, 3))], axis=1).astype(np.float32)
+    X[::7, :3] *= 1e-3                       # a mix: some rows inside the recurrence range
+    X[5, 0], X[6, 1] = 0.0, np.float32(1e-30)
+    for Lp, Ld in [(16, 8), (22, 3), (30, 30)]:   # the last: rows of 366 floats, 32 points per workgroup
+        pe_dim = 3 + 6 * Lp + 3 + 6 * Ld
+        d_x, d_pe = DeviceArray.from_numpy(X), DeviceArray((n, pe_dim))
+        assert lib.nerf_encode_points(d_x.ptr, n, Lp, Ld, d_pe.ptr, pe_dim) == 0
+        ope = oracle.batch_positional_encoding(X, n, 1, Lp, Ld)
+        tm = trig_mask(pe_dim, Lp, Ld)
+        pe = d_pe.numpy()
+        assert np.array_equal(pe[:, ~tm], ope[:, ~tm])
+        np.testing.assert_allclose(pe[:, tm], ope[:, tm], rtol=0, atol=TRIG_ATOL)
+
+
 def test_page_locked_buffers_and_kept_staging(gpu):
     """nerf_host_alloc buffers (a drop-in for train.c:135-137's malloc) through the host-pointer
     functions: same bytes as from pageable memory; the staging buffers survive growing, shrinking and
