@@ -73,7 +73,7 @@ struct GemmArgs {
     int epilogue;
     int splits;       // EPI_SPLITK: number of contraction chunks (C = slabs base, chunk s at C + s*M*ldc)
     int k_chunk;      // EPI_SPLITK: contraction rows per chunk (multiple of 32)
-    int tile_n;       // EPI_SPLITK: output tile width the caller planned with (128, 160; 256: split-bf16 only)
+    int tile_n;       // EPI_SPLITK: output tile width the caller planned with (64, 128, 160; 256: split-bf16 only)
     // split-bf16 kernels only.  A "split word" holds one value as (bf16 head << 16) | bf16 remainder --
     // the two halves the split-bf16 product works with, in the 4 bytes of the float they came from.
     int operands_split;  // A and B hold split words: the loop only unpacks them

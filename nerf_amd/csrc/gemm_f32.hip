@@ -90,7 +90,7 @@ template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int BKT = BK>
 __global__ __launch_bounds__(256, BKT == 32 ? 2 : 3) void gemm_dma_kernel(const KernelArgs ka) {
     constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32;
     constexpr int A_TILE = BM_ * BKT, B_TILE = BN_ * BKT;
-    static_assert(WM * WN == 4 && BM_ == 128, "four wavefronts, 128-row tiles");
+    static_assert(WM * WN == 4 && (BM_ == 128 || BM_ == 64), "four wavefronts, 128- or 64-row tiles");
     __shared__ __attribute__((aligned(16))) float lds[2][A_TILE + B_TILE];
     const GemmArgs& p = ka.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, BKT == 32 ? 2 : 3) void gemm_dma_kernel(const 
         k_tile<A_KC, B_KC, WM, WN, MI, NI, 1, BKT>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, wm, wn, lane);
     }
     if (kt < nkt) k_tile<A_KC, B_KC, WM, WN, MI, NI, 0, BKT>(lds, da, db, acc, kt, wave, wm, wn, lane);
-    epilogue<MI, NI>(p, acc, m0, n0, split, wm * MI * 32, wn * NI * 32, lane);
+    epilogue<MI, NI>(p, acc, m0, n0, split, wm * MI * 32, wn * NI * 32, lane, BM_);
 }
 
 // explicit instantiations (hipcc 7.2 drops the host stubs of some implicitly instantiated variants)
@@ -139,6 +139,10 @@ template __global__ void gemm_dma_kernel<false, false, 2, 2, 2, 2>(const KernelA
 template __global__ void gemm_dma_kernel<false, false, 4, 1, 1, 5>(const KernelArgs);
 template __global__ void gemm_dma_kernel<true, true, 2, 2, 2, 2, 16>(const KernelArgs);
 template __global__ void gemm_dma_kernel<true, false, 2, 2, 2, 2, 16>(const KernelArgs);
+// 64x64 tiles (one MFMA tile per wavefront) for products too small to fill the chip with 128x128 ones
+template __global__ void gemm_dma_kernel<true, true, 2, 2, 1, 1, 16>(const KernelArgs);
+template __global__ void gemm_dma_kernel<true, false, 2, 2, 1, 1, 16>(const KernelArgs);
+template __global__ void gemm_dma_kernel<false, false, 2, 2, 1, 1, 16>(const KernelArgs);
 
 // ================================================================================================
 // Generic path: guarded buffer loads -> registers -> LDS, 128x128 tiles
@@ -369,6 +373,10 @@ template <bool A_KC, bool B_KC>
 void launch_dma16(const KernelArgs& ka, int grid) {
     hipLaunchKernelGGL((gemm_dma_kernel<A_KC, B_KC, 2, 2, 2, 2, 16>), dim3(grid), dim3(256), 0, stream(), ka);
 }
+template <bool A_KC, bool B_KC>
+void launch_dma_small(const KernelArgs& ka, int grid) {
+    hipLaunchKernelGGL((gemm_dma_kernel<A_KC, B_KC, 2, 2, 1, 1, 16>), dim3(grid), dim3(256), 0, stream(), ka);
+}
 
 // does an operand meet the DMA path's needs: 16-byte aligned base and rows; for KS also a row count
 // that keeps 16-byte pieces inside the matrix (x advances in fours: X may be ragged only if the
@@ -414,8 +422,14 @@ int gemm_f32(const GemmArgs& g) {
                      dma_operand_ok(g.B, g.ldb, g.b_kc, g.N, g.K);
     // the 160-wide tile exists for the split-K weight gradient (both operands strided)
     const bool wide = dma && g.epilogue == EPI_SPLITK && !g.a_kc && !g.b_kc && g.tile_n == 160;
-    ka.tiles_m = (g.M + 127) / 128;
-    ka.tiles_n = wide ? (g.N + 159) / 160 : (g.N + 127) / 128;
+    // 64x64 tiles when 128x128 ones would not give every CU its four workgroups (a 2048-point batch
+    // is 16 x 4 of them and each walks the whole contraction alone; measured: the small tiles win
+    // below 1024 large ones): a split-K caller says so in its plan, any other product is sized here
+    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const bool small = dma && !wide && (g.epilogue == EPI_SPLITK ? g.tile_n == 64 : (g.a_kc && tiles128 < 1024));
+    const int edge = small ? 64 : 128;
+    ka.tiles_m = (g.M + edge - 1) / edge;
+    ka.tiles_n = wide ? (g.N + 159) / 160 : (g.N + edge - 1) / edge;
     long grid = (long)ka.tiles_m * ka.tiles_n;
     if (g.epilogue == EPI_SPLITK) grid *= g.splits;
     if (grid > 0x7fffffffL) return NERF_ERR_ARG;
@@ -425,6 +439,9 @@ int gemm_f32(const GemmArgs& g) {
         // point-major result: more co-resident workgroups hide the epilogue's stores.  The
         // weight gradient (both operands strided, slab epilogue) is faster on 32-step tiles.
         if (wide) launch_dma<false, false, 4, 1, 1, 5>(ka, gi);
+        else if (small && g.a_kc && g.b_kc) launch_dma_small<true, true>(ka, gi);
+        else if (small && g.a_kc) launch_dma_small<true, false>(ka, gi);
+        else if (small) launch_dma_small<false, false>(ka, gi);
         else if (g.a_kc && g.b_kc) launch_dma16<true, true>(ka, gi);
         else if (g.a_kc) launch_dma16<true, false>(ka, gi);
         else launch_dma<false, false, 2, 2, 2, 2>(ka, gi);

@@ -186,7 +186,10 @@ bool skinny_ok(int hidden, int out_dim) { return skinny_ok_impl(hidden, out_dim)
 
 void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int hidden, int out_dim, bool from_preact) {
     ProfScope prof(K_SKINNY_FWD, (double)rows * (hidden + out_dim) * 4.0);
-    long blocks = (rows + 127) / 128;  // 8 iterations of 16 points per workgroup
+    // 16 points per workgroup and iteration; up to 8 iterations, fewer while that leaves under 1024 workgroups
+    long iters = rows / (16 * 1024);
+    iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+    long blocks = (rows + 16 * iters - 1) / (16 * iters);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     const size_t lds = (size_t)out_dim * hidden * sizeof(float);
@@ -263,6 +266,17 @@ WgradPlan plan_weight_gradient(int rows_out, int cols, long batch) {
     pl.tile_n = wgrad_tile_n(cols);
     const int tiles = ((rows_out + 127) / 128) * ((cols + pl.tile_n - 1) / pl.tile_n);
     pl.splits = choose_splits(tiles, batch, &pl.k_chunk);
+    if ((long)tiles * pl.splits < 256) {
+        // a short batch cannot be split far enough to fill the chip with 128-wide tiles: 64x64 ones
+        const int tiles64 = ((rows_out + 63) / 64) * ((cols + 63) / 64);
+        int k_chunk;
+        const int splits = choose_splits(tiles64, batch, &k_chunk);
+        if ((long)tiles64 * splits > (long)tiles * pl.splits) {
+            pl.tile_n = 64;
+            pl.splits = splits;
+            pl.k_chunk = k_chunk;
+        }
+    }
     return pl;
 }
 

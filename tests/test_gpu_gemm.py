@@ -39,6 +39,9 @@ CASES = [
     (300, 256, 16, 1, 1),      # a single 16-step K-tile on the DMA path
     (300, 256, 48, 1, 0),      # odd number of 16-step K-tiles (the loop is unrolled by two)
     (257, 130, 144, 1, 1),     # K a multiple of 16 but not of 32, ragged rows and columns
+    # the cases above are small enough for 64x64 tiles; these two fill the chip and take 128x128 ones
+    (32770, 512, 96, 1, 1),
+    (32770, 500, 80, 1, 0),
 ]
 
 
