@@ -272,13 +272,18 @@ const unsigned short* nerf_trainer_buffer_bf16(NerfTrainer* tr, int which);
 int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
                      float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
                      unsigned char* host_rgb8, float* host_pixel);
-/* The same with fuse_linear_pair = 1: mlp1's output layer and mlp2's input layer run as one product
- * through Wc = W1b W2a (see NerfTrainerConfig.fuse_linear_pair): a third fewer FLOPs per point, pixel
- * values equal to fp32 rounding.  The products use each MLP's matrix arithmetic
- * (nerf_mlp_set_matrix_math) in both functions.  No counterpart in the reference. */
+/* The same with options (a sum of the flags below; 0 = nerf_render_view).  No counterpart in the reference.
+ *   NERF_RENDER_FUSE_LINEAR_PAIR   mlp1's output layer and mlp2's input layer run as one product through
+ *                                  Wc = W1b W2a (see NerfTrainerConfig.fuse_linear_pair): a third fewer
+ *                                  FLOPs per point, pixel values equal to fp32 rounding.
+ *   NERF_RENDER_SPACING_QUADRATURE composite with the true sample spacing and no early stop
+ *                                  (nerf_composite_forward_spacing, uniform depths): the renderer for
+ *                                  a model trained with NERF_QUADRATURE_SPACING.
+ * The products use each MLP's matrix arithmetic (nerf_mlp_set_matrix_math) in both functions. */
+enum { NERF_RENDER_FUSE_LINEAR_PAIR = 1, NERF_RENDER_SPACING_QUADRATURE = 2 };
 int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
-                          unsigned char* host_rgb8, float* host_pixel, int fuse_linear_pair);
+                          unsigned char* host_rgb8, float* host_pixel, int options);
 
 #ifdef __cplusplus
 }

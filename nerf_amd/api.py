@@ -294,14 +294,14 @@ class Trainer:
             off += s[0] * s[1]
         return out
 
-    def render_view(self, cam, width, height, rays_per_chunk=4096, fuse_linear_pair=False):
+    def render_view(self, cam, width, height, rays_per_chunk=4096, fuse_linear_pair=False, spacing_quadrature=False):
         rgb8 = np.empty((height, width, 3), np.uint8)
         pix = np.empty((height, width, 3), np.float32)
         c = self.cfg
         _check(lib.nerf_render_view_opts(lib.nerf_trainer_mlp(self.handle, 0), lib.nerf_trainer_mlp(self.handle, 1),
                                          C.byref(cam), width, height, c.num_samples, c.near_plane, c.far_plane,
                                          c.pos_enc_l, c.dir_enc_l, rays_per_chunk, rgb8.ctypes.data, pix.ctypes.data,
-                                         int(fuse_linear_pair)),
+                                         int(bool(fuse_linear_pair)) | (2 if spacing_quadrature else 0)),
                "nerf_render_view_opts")
         return rgb8, pix
 

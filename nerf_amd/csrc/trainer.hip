@@ -546,10 +546,12 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
 
 int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
-                          unsigned char* host_rgb8, float* host_pixel, int fuse_linear_pair) {
+                          unsigned char* host_rgb8, float* host_pixel, int options) {
     if (!mlp1 || !mlp2 || !cam || render_w <= 0 || render_h <= 0 || num_samples <= 1 || num_samples > 1024)
         return NERF_ERR_ARG;
-    if (fuse_linear_pair != 0 && fuse_linear_pair != 1) return NERF_ERR_ARG;
+    if (options & ~(NERF_RENDER_FUSE_LINEAR_PAIR | NERF_RENDER_SPACING_QUADRATURE)) return NERF_ERR_ARG;
+    const int fuse_linear_pair = (options & NERF_RENDER_FUSE_LINEAR_PAIR) != 0;
+    const bool spacing = (options & NERF_RENDER_SPACING_QUADRATURE) != 0;
     if (fuse_linear_pair && !skinny_ok(mlp2->hidden_dim, mlp2->output_dim)) return NERF_ERR_ARG;
     const int pe_dim = NERF_PE_DIM3(pos_enc_l) + NERF_PE_DIM3(dir_enc_l);
     if (mlp1->input_dim != pe_dim || mlp2->input_dim != mlp1->output_dim || mlp2->output_dim < 4) return NERF_ERR_ARG;
@@ -638,8 +640,10 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
             mlp_forward(r2, r1->d_layer_output);
         }
         ProfScope prof(K_COMPOSITE_FWD, (double)count * num_samples * 16.0);
-        rc = nerf_composite_forward(r2->d_layer_output, r2->output_dim, nullptr, 0, nullptr, nullptr,
-                                    d_pixel + (size_t)first * 3, nullptr, count, num_samples);
+        rc = spacing ? nerf_composite_forward_spacing(r2->d_layer_output, r2->output_dim, nullptr, near_plane, far_plane,
+                                                      nullptr, 0, d_pixel + (size_t)first * 3, nullptr, count, num_samples)
+                     : nerf_composite_forward(r2->d_layer_output, r2->output_dim, nullptr, 0, nullptr, nullptr,
+                                              d_pixel + (size_t)first * 3, nullptr, count, num_samples);
     }
     if (rc == NERF_OK) {
         hipLaunchKernelGGL(quantize_kernel, dim3((total * 3 + 255) / 256), dim3(256), 0, stream(), d_pixel, d_rgb8,

@@ -84,3 +84,51 @@ def test_trainer_with_spacing_quadrature_and_jitter(gpu, oracle):
     # the reference mode refuses nothing, the spacing mode refuses host-supplied points (it needs depths)
     assert lib.nerf_trainer_forward_backward_points(tr.handle, DeviceArray.from_numpy(X).ptr,
                                                     DeviceArray.from_numpy(col[::S]).ptr) == 1
+
+
+def test_render_with_spacing_quadrature(gpu, oracle):
+    """nerf_render_view_opts(NERF_RENDER_SPACING_QUADRATURE): the view composited with the true sample
+    spacing and no early stop, against the oracle's spacing quadrature on the oracle's own densities
+    and colours; different from the reference compositing of the same field"""
+    from oracle.pyoracle import ACC_F64
+    from nerf_amd.api import make_camera
+    from conftest import make_scene
+    from test_gpu_render import setup_pair
+    S, rw, rh, Lp, Ld, hidden, inter = 48, 12, 9, 6, 3, 128, 64
+    tr, parts = setup_pair(gpu, oracle, S, hidden=hidden, inter=inter, Lp=Lp, Ld=Ld, density_gain=60.0)
+    cams, _ = make_scene(1, 40, 30)
+    pos, rot, focal, w, h = cams[0]
+    _, pix = tr.render_view(make_camera(*cams[0]), rw, rh, rays_per_chunk=50, spacing_quadrature=True)
+    _, pix_ref_mode = tr.render_view(make_camera(*cams[0]), rw, rh, rays_per_chunk=50)
+    # the oracle: same rays, its MLPs, then its spacing quadrature on the activated outputs
+    ocam = oracle.camera(pos, rot, focal, w, h)
+    idx = np.empty((rw * rh, 3), np.int32)
+    for v in range(rh):
+        for u in range(rw):
+            idx[v * rw + u] = (0, int(np.float32(np.float32(u) * np.float32(w)) / np.float32(rw)),
+                               int(np.float32(np.float32(v) * np.float32(h)) / np.float32(rh)))
+    X, _ = oracle.batch_from_indices([ocam], [np.zeros((h, w, 4), np.uint8)], idx, S, 2.0, 6.0)
+    R = rw * rh
+    pe = 3 + 6 * Lp + 3 + 6 * Ld
+    m1 = oracle.init_mlp(pe, hidden, inter, R * S, acc_mode=ACC_F64)
+    m2 = oracle.init_mlp(inter, hidden, 4, R * S, acc_mode=ACC_F64)
+    a1, a2 = oracle.mlp_arrays(m1), oracle.mlp_arrays(m2)
+    a1["W1"][:], a1["W2"][:], a2["W1"][:], a2["W2"][:] = parts
+    buf = oracle.alloc_step(R, S, Lp, Ld)
+    oracle.render_rays(m1, m2, buf, X)
+    arr = oracle.step_arrays(buf)
+    want, _, _ = oracle.composite_spacing(arr["dens"].copy(), arr["rgb"].copy(), np.zeros((R * S, 3), np.float32), R, S,
+                                          2.0, 6.0)
+    oracle.free_step(buf)
+    oracle.free_mlp(m1)
+    oracle.free_mlp(m2)
+    want = want.reshape(rh, rw, 3)
+    assert want.max() > 0.1
+    np.testing.assert_allclose(pix, want, rtol=1e-4, atol=2e-6)
+    assert np.abs(pix - pix_ref_mode).max() > 1e-2   # the two quadratures are different pictures
+    # unknown option bits are refused
+    from nerf_amd._lib import lib
+    import ctypes as C
+    rc = lib.nerf_render_view_opts(lib.nerf_trainer_mlp(tr.handle, 0), lib.nerf_trainer_mlp(tr.handle, 1),
+                                   C.byref(make_camera(*cams[0])), rw, rh, S, 2.0, 6.0, Lp, Ld, 50, None, None, 4)
+    assert rc != 0
