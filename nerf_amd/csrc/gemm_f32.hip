@@ -48,16 +48,10 @@ constexpr int KC_LD = BK + 4;  // generic kernel: floats per LDS row of a KC til
 // ================================================================================================
 // One K-tile: start the DMA of tile `next` into the other buffer, run the BKT contraction steps of
 // buffer CUR, barrier.  (`next` past the end re-fetches the last tile; it is never read.)
-template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int CUR, int BKT>
-__device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 * BKT],
-                                       const DmaLoader<A_KC, WM * MI * 32, 256, BKT>& da,
-                                       const DmaLoader<B_KC, WN * NI * 32, 256, BKT>& db, f32x16 (&acc)[MI][NI], int next,
-                                       int wave, int wm, int wn, int lane) {
-    constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32, A_TILE = BM_ * BKT;
-    da.issue(lds[CUR ^ 1], next, wave);
-    db.issue(lds[CUR ^ 1] + A_TILE, next, wave);
-    const float* TA = lds[CUR];
-    const float* TB = lds[CUR] + A_TILE;
+// the BKT contraction steps of one staged tile pair
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int BKT>
+__device__ __forceinline__ void k_compute(const float* TA, const float* TB, f32x16 (&acc)[MI][NI], int wm, int wn, int lane) {
+    constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32;
     float fa[2][MI][4], fb[2][NI][4];
 #pragma unroll
     for (int i = 0; i < MI; i++) dma_frag<A_KC, BM_, BKT>(fa[0][i], TA, wm * MI * 32 + i * 32, 0, lane);
@@ -83,6 +77,17 @@ __device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 
                 for (int ni = 0; ni < NI; ni++)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][mi][j], fb[c][ni][j], acc[mi][ni], 0, 0, 0);
     }
+}
+
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int CUR, int BKT>
+__device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 * BKT],
+                                       const DmaLoader<A_KC, WM * MI * 32, 256, BKT>& da,
+                                       const DmaLoader<B_KC, WN * NI * 32, 256, BKT>& db, f32x16 (&acc)[MI][NI], int next,
+                                       int wave, int wm, int wn, int lane) {
+    constexpr int A_TILE = WM * MI * 32 * BKT;
+    da.issue(lds[CUR ^ 1], next, wave);
+    db.issue(lds[CUR ^ 1] + A_TILE, next, wave);
+    k_compute<A_KC, B_KC, WM, WN, MI, NI, BKT>(lds[CUR], lds[CUR] + A_TILE, acc, wm, wn, lane);
     __syncthreads();
 }
 
