@@ -95,12 +95,20 @@ __device__ __forceinline__ void nt_tile(float (&lds)[2][(WM * MI + WN * NI) * 32
     __syncthreads();
 }
 
-// Epilogue of the k-contiguous products: lane owns point m = lane & 31 of each 32-point block and, per
-// register group q = r >> 2, the 4 consecutive features n = 8q + 4 (lane >> 5) + (0..3): 8 bytes of a bf16 row.
+// Epilogue of the k-contiguous products.  In the accumulators a lane owns point m = lane & 31 of each
+// 32-point block and, per register group q = r >> 2, the 4 consecutive features 8q + 4 (lane >> 5) + (0..3):
+// stored from there, one instruction would touch 32 rows with 16 bytes each.  The wavefront's tile
+// (MI*32 points x 64 features = one 128-byte line of bf16 per point) is therefore passed through the
+// wavefront's own 16 KB of LDS (the operand buffers are free after the K loop): written in the
+// accumulator layout, read back row by row, so that every global instruction -- the stores, and the
+// loads of the pre-activation for the swish' epilogue, which take the same way in the other
+// direction -- moves whole 128-byte lines, 4 rows per instruction.  LDS image: [row][16 chunks of
+// 8 bytes], chunk c of row r at c ^ (r & 15): conflict-free for both access patterns.
 template <int WM, int WN, int MI, int NI>
-__device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&acc)[NI][MI], int m0, int n0, int wm, int wn,
-                                              int lane) {
-    constexpr int BM_ = WM * MI * 32;
+__device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&acc)[NI][MI], float* lds_base, int m0,
+                                              int n0, int wave, int wm, int wn, int lane) {
+    static_assert(NI == 2, "a wavefront's tile is 64 features wide");
+    constexpr int BM_ = WM * MI * 32, ROWS = MI * 32;
     const int rows_here = (p.M - m0) < BM_ ? (p.M - m0) : BM_;
     const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 2u;
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
@@ -109,33 +117,54 @@ __device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&ac
         (void*)((p.epilogue == EPI_SWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((p.epilogue == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+    u32x2* stage = reinterpret_cast<u32x2*>(lds_base) + wave * (ROWS * 16);
+    // row-wise view: lane = (row within a group of 4, 8-byte chunk of the line)
+    const int rsub = lane >> 4, cch = lane & 15;
+    const int ncol = n0 + wn * 64 + cch * 4;
+    const unsigned col_off = (ncol + 3 < p.N) ? (unsigned)ncol * 2u : OOR;
+    const unsigned row_bytes = (unsigned)p.ldc * 2u;
+    if (p.epilogue == EPI_DSWISH_MUL) {
+#pragma unroll 8
+        for (int it = 0; it < ROWS / 4; it++) {
+            const int row = it * 4 + rsub;
+            const unsigned voff = col_off == OOR ? OOR : (unsigned)(wm * ROWS + row) * row_bytes + col_off;
+            stage[row * 16 + (cch ^ (row & 15))] =
+                __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rAUX, voff, 0, 0));
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
-        const int m_local = (wm * MI + mi) * 32 + (lane & 31);
+        const int row = mi * 32 + (lane & 31);
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
-            const int n_first = n0 + (wn * NI + ni) * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int n = n_first + 8 * q;
-                const unsigned voff = (n + 3 < p.N) ? (unsigned)(m_local * p.ldc + n) * 2u : OOR;
+                const int c = ni * 8 + 2 * q + (lane >> 5);
+                u32x2* slot = stage + row * 16 + (c ^ (row & 15));
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[ni][mi][4 * q + e];
                 if (p.epilogue == EPI_DSWISH_MUL) {
-                    const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rAUX, voff, 0, 0));
+                    const u32x2 a = *slot;
                     v[0] *= dswish_f(bf16_lo(a[0])); v[1] *= dswish_f(bf16_hi(a[0]));
                     v[2] *= dswish_f(bf16_lo(a[1])); v[3] *= dswish_f(bf16_hi(a[1]));
                 }
-                u32x2 out = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(out, rC, voff, 0, 0);
-                if (p.epilogue == EPI_SWISH) {
-                    // the activation of the ROUNDED pre-activation: what the backward pass will recompute from
-                    const u32x2 act = {pack_bf16(swish_f(bf16_lo(out[0])), swish_f(bf16_hi(out[0]))),
-                                       pack_bf16(swish_f(bf16_lo(out[1])), swish_f(bf16_hi(out[1])))};
-                    __builtin_amdgcn_raw_buffer_store_b64(act, rC2, voff, 0, 0);
-                }
+                const u32x2 out = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                *slot = out;
             }
+        }
+    }
+#pragma unroll 8
+    for (int it = 0; it < ROWS / 4; it++) {
+        const int row = it * 4 + rsub;
+        const unsigned voff = col_off == OOR ? OOR : (unsigned)(wm * ROWS + row) * row_bytes + col_off;
+        const u32x2 out = stage[row * 16 + (cch ^ (row & 15))];
+        __builtin_amdgcn_raw_buffer_store_b64(out, rC, voff, 0, 0);
+        if (p.epilogue == EPI_SWISH) {
+            // the activation of the ROUNDED pre-activation: what the backward pass will recompute from
+            const u32x2 act = {pack_bf16(swish_f(bf16_lo(out[0])), swish_f(bf16_hi(out[0]))),
+                               pack_bf16(swish_f(bf16_lo(out[1])), swish_f(bf16_hi(out[1])))};
+            __builtin_amdgcn_raw_buffer_store_b64(act, rC2, voff, 0, 0);
         }
     }
 }
@@ -187,7 +216,7 @@ __global__ __launch_bounds__(WM * WN * 64, 512 / (WM * WN * 64)) void gemm_bf16_
     }
     if (kt < nkt) nt_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, wm, wn, lane);
 
-    nt_store_tile<WM, WN, MI, NI>(p, acc, m0, n0, wm, wn, lane);
+    nt_store_tile<WM, WN, MI, NI>(p, acc, &lds[0][0], m0, n0, wave, wm, wn, lane);
 }
 
 // ================================================================================================
