@@ -43,6 +43,8 @@ def main():
                     help="reference: the reference's compositing and gradient (nerf.c:21-127).  spacing: this "
                          "library's opt-in true-spacing quadrature with the analytic gradient, rendered the same way")
     ap.add_argument("--stratified", action="store_true", help="jitter the sample depths (spacing quadrature only)")
+    ap.add_argument("--eval-views", type=int, default=0,
+                    help="at the end, also render this many evenly spaced views and report their mean PSNR")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out", default="gpurun_out/scene")
     args = ap.parse_args()
@@ -99,6 +101,20 @@ def main():
         else:
             t_train += time.perf_counter() - t0
 
+    final = {}
+    if args.eval_views > 0:
+        per_view = []
+        for v in np.linspace(0, n_img - 1, args.eval_views).astype(int):
+            cam = ds.contents.cameras[v].contents
+            img = np.ctypeslib.as_array(ds.contents.images[v].contents.data, shape=(H, W, 4))
+            _, px = tr.render_view(cam, rw, rh, rays_per_chunk=4096, fuse_linear_pair=args.fuse_linear_pair,
+                                   spacing_quadrature=spacing)
+            per_view.append(psnr(np.clip(px.reshape(rh, rw, 3), 0, 1), img[::4, ::4, :3].astype(np.float32) / 255.0))
+        final = {"eval_views": [int(v) for v in np.linspace(0, n_img - 1, args.eval_views).astype(int)],
+                 "psnr_per_view": per_view, "psnr_mean": float(np.mean(per_view))}
+        print(f"PSNR over {args.eval_views} views: mean {final['psnr_mean']:.2f} dB, "
+              f"min {min(per_view):.2f}, max {max(per_view):.2f}", flush=True)
+
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     side = np.concatenate([rgb8.reshape(rh, rw, 3), (target * 255).astype(np.uint8)], axis=1)
     png = (args.out + "_view0.png").encode()
@@ -106,7 +122,7 @@ def main():
     print(json.dumps({"scene": os.path.basename(os.path.abspath(args.data)), "views": n_img, "rays_per_step": args.rays,
                       "samples": args.samples, "steps": args.steps, "lr": args.lr, "math": args.math,
                       "fuse_linear_pair": bool(args.fuse_linear_pair), "quadrature": args.quadrature,
-                      "stratified": bool(args.stratified), "log": log}), flush=True)
+                      "stratified": bool(args.stratified), "log": log, **final}), flush=True)
     lib.nerf_dataset_release(dds)
     lib.free_dataset(ds)
 
