@@ -139,7 +139,42 @@ __device__ __forceinline__ void dma_frag(float (&frag)[4], const float* __restri
 // Accumulator register r of a 32x32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
 // Buffer stores: the per-lane offset is computed once, the per-register part is a scalar offset,
 // rows past M fall outside the descriptor and columns past N carry an out-of-range offset -- no
-// per-element address arithmetic or branches.
+// per-element address arithmetic or branches.  The kind of epilogue and the output formats are
+// decided ONCE, in epilogue(), which jumps into one of six straight-line bodies: tested per
+// element instead, the unrolled code is some 600 basic blocks whose instruction fetch, not the
+// stores, sets the pace of a workgroup's last phase.
+template <int MI, int NI, int EPI, bool C_SPLIT, bool C2_SPLIT>
+__device__ __forceinline__ void epilogue_body(f32x16 (&acc)[MI][NI], __amdgpu_buffer_rsrc_t rC, __amdgpu_buffer_rsrc_t rC2,
+                                              __amdgpu_buffer_rsrc_t rAUX, const unsigned (&voff)[NI], unsigned row_bytes) {
+#pragma unroll
+    for (int mi = 0; mi < MI; mi++) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ni++) {
+            float aux[16];
+            if (EPI == EPI_DSWISH_MUL) {  // all loads first: the stores may alias them as far as the compiler knows
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
+                    aux[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAUX, voff[ni], soff, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
+                float x = acc[mi][ni][r];
+                if (EPI == EPI_DSWISH_MUL) x *= dswish_f(aux[r]);
+                __builtin_amdgcn_raw_buffer_store_b32(C_SPLIT ? split_word(x) : __builtin_bit_cast(unsigned, x), rC, voff[ni],
+                                                      soff, 0);
+                if (EPI == EPI_SWISH) {
+                    const float a = swish_f(x);
+                    __builtin_amdgcn_raw_buffer_store_b32(C2_SPLIT ? split_word(a) : __builtin_bit_cast(unsigned, a), rC2,
+                                                          voff[ni], soff, 0);
+                }
+            }
+        }
+    }
+}
+
 template <int MI, int NI>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[MI][NI], int m0, int n0, int split,
                                          int wrow, int wcol, int lane, int tile_rows = 128) {
@@ -163,45 +198,14 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, f32x16 (&acc)[MI][NI
     }
     const unsigned row_bytes = (unsigned)p.ldc * 4u;
     if (p.epilogue == EPI_DSWISH_MUL) {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-                float aux[16];  // all loads first: the stores may alias them as far as the compiler knows
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
-                    aux[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAUX, voff[ni], soff, 0));
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
-                    const float o = acc[mi][ni][r] * dswish_f(aux[r]);
-                    __builtin_amdgcn_raw_buffer_store_b32(p.c_split ? split_word(o) : __builtin_bit_cast(unsigned, o), rC,
-                                                          voff[ni], soff, 0);
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int mi = 0; mi < MI; mi++) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ni++) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const unsigned soff = (unsigned)(mi * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes;
-                    const float x = acc[mi][ni][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(
-                        p.c_split && p.epilogue == EPI_STORE ? split_word(x) : __builtin_bit_cast(unsigned, x), rC,
-                        voff[ni], soff, 0);
-                    if (p.epilogue == EPI_SWISH) {
-                        const float a = swish_f(x);
-                        __builtin_amdgcn_raw_buffer_store_b32(p.c2_split ? split_word(a) : __builtin_bit_cast(unsigned, a),
-                                                              rC2, voff[ni], soff, 0);
-                    }
-                }
-            }
-        }
+        if (p.c_split) epilogue_body<MI, NI, EPI_DSWISH_MUL, true, false>(acc, rC, rC2, rAUX, voff, row_bytes);
+        else epilogue_body<MI, NI, EPI_DSWISH_MUL, false, false>(acc, rC, rC2, rAUX, voff, row_bytes);
+    } else if (p.epilogue == EPI_SWISH) {  // the pre-activation is never wanted as split words
+        if (p.c2_split) epilogue_body<MI, NI, EPI_SWISH, false, true>(acc, rC, rC2, rAUX, voff, row_bytes);
+        else epilogue_body<MI, NI, EPI_SWISH, false, false>(acc, rC, rC2, rAUX, voff, row_bytes);
+    } else if (p.epilogue == EPI_STORE && p.c_split) {
+        epilogue_body<MI, NI, EPI_STORE, true, false>(acc, rC, rC2, rAUX, voff, row_bytes);
+    } else {  // EPI_STORE, EPI_SPLITK
+        epilogue_body<MI, NI, EPI_STORE, false, false>(acc, rC, rC2, rAUX, voff, row_bytes);
     }
 }
-
