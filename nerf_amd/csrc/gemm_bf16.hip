@@ -104,8 +104,8 @@ __device__ __forceinline__ void nt_tile(float (&lds)[2][(WM * MI + WN * NI) * 32
 // loads of the pre-activation for the swish' epilogue, which take the same way in the other
 // direction -- moves whole 128-byte lines, 4 rows per instruction.  LDS image: [row][16 chunks of
 // 8 bytes], chunk c of row r at c ^ (r & 15): conflict-free for both access patterns.
-template <int WM, int WN, int MI, int NI>
-__device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&acc)[NI][MI], float* lds_base, int m0,
+template <int WM, int WN, int MI, int NI, int EPI>
+__device__ __forceinline__ void nt_store_body(const GemmBf16Args& p, f32x16 (&acc)[NI][MI], float* lds_base, int m0,
                                               int n0, int wave, int wm, int wn, int lane) {
     static_assert(NI == 2, "a wavefront's tile is 64 features wide");
     constexpr int BM_ = WM * MI * 32, ROWS = MI * 32;
@@ -114,16 +114,16 @@ __device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&ac
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.C + (size_t)m0 * p.ldc), 0, p.C ? panel_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((p.epilogue == EPI_SWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+        (void*)((EPI == EPI_SWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((p.epilogue == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+        (void*)((EPI == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
     u32x2* stage = reinterpret_cast<u32x2*>(lds_base) + wave * (ROWS * 16);
     // row-wise view: lane = (row within a group of 4, 8-byte chunk of the line)
     const int rsub = lane >> 4, cch = lane & 15;
     const int ncol = n0 + wn * 64 + cch * 4;
     const unsigned col_off = (ncol + 3 < p.N) ? (unsigned)ncol * 2u : OOR;
     const unsigned row_bytes = (unsigned)p.ldc * 2u;
-    if (p.epilogue == EPI_DSWISH_MUL) {
+    if (EPI == EPI_DSWISH_MUL) {
 #pragma unroll 8
         for (int it = 0; it < ROWS / 4; it++) {
             const int row = it * 4 + rsub;
@@ -144,7 +144,7 @@ __device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&ac
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = acc[ni][mi][4 * q + e];
-                if (p.epilogue == EPI_DSWISH_MUL) {
+                if (EPI == EPI_DSWISH_MUL) {
                     const u32x2 a = *slot;
                     v[0] *= dswish_f(bf16_lo(a[0])); v[1] *= dswish_f(bf16_hi(a[0]));
                     v[2] *= dswish_f(bf16_lo(a[1])); v[3] *= dswish_f(bf16_hi(a[1]));
@@ -160,13 +160,23 @@ __device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&ac
         const unsigned voff = col_off == OOR ? OOR : (unsigned)(wm * ROWS + row) * row_bytes + col_off;
         const u32x2 out = stage[row * 16 + (cch ^ (row & 15))];
         __builtin_amdgcn_raw_buffer_store_b64(out, rC, voff, 0, 0);
-        if (p.epilogue == EPI_SWISH) {
+        if (EPI == EPI_SWISH) {
             // the activation of the ROUNDED pre-activation: what the backward pass will recompute from
             const u32x2 act = {pack_bf16(swish_f(bf16_lo(out[0])), swish_f(bf16_hi(out[0]))),
                                pack_bf16(swish_f(bf16_lo(out[1])), swish_f(bf16_hi(out[1])))};
             __builtin_amdgcn_raw_buffer_store_b64(act, rC2, voff, 0, 0);
         }
     }
+}
+
+// the kind of epilogue is decided once: each body is straight-line code
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&acc)[NI][MI], float* lds_base, int m0,
+                                              int n0, int wave, int wm, int wn, int lane) {
+    if (p.epilogue == EPI_SWISH) nt_store_body<WM, WN, MI, NI, EPI_SWISH>(p, acc, lds_base, m0, n0, wave, wm, wn, lane);
+    else if (p.epilogue == EPI_DSWISH_MUL)
+        nt_store_body<WM, WN, MI, NI, EPI_DSWISH_MUL>(p, acc, lds_base, m0, n0, wave, wm, wn, lane);
+    else nt_store_body<WM, WN, MI, NI, EPI_STORE>(p, acc, lds_base, m0, n0, wave, wm, wn, lane);
 }
 
 template <int WM, int WN, int MI, int NI>
