@@ -125,3 +125,23 @@ def test_driver_rejects_bad_usage_and_bad_checkpoints(gpu, tmp_path):
     p = subprocess.run([TRAIN, "--data", str(tmp_path / "nowhere")], cwd=str(tmp_path), capture_output=True, text=True,
                        timeout=110)
     assert p.returncode != 0  # train.c:35-38
+
+
+def test_scene_training_tool(gpu, tmp_path):
+    """tools/train_scene.py on a small scene on disk: both quadratures run, report a loss and a PSNR
+    per checkpoint, write the side-by-side picture, and the loss goes down"""
+    import sys
+    write_scene(str(tmp_path), n=4, size=(40, 32))
+    tool = os.path.join(ROOT, "tools", "train_scene.py")
+    for extra in ([], ["--quadrature", "spacing", "--stratified", "--math", "split-bf16", "--fuse-linear-pair"]):
+        out = str(tmp_path / "scene")
+        p = subprocess.run([sys.executable, tool, "--data", str(tmp_path), "--images", "4", "--rays", "64", "--samples", "32",
+                            "--steps", "60", "--report", "20", "--eval-views", "2", "--out", out] + extra,
+                           capture_output=True, text=True, timeout=110)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        rec = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert [e["step"] for e in rec["log"]] == [20, 40, 60]
+        assert all(np.isfinite(e["loss_per_ray"]) and np.isfinite(e["psnr_view0"]) for e in rec["log"])
+        assert rec["log"][-1]["loss_per_ray"] < rec["log"][0]["loss_per_ray"]
+        assert len(rec["psnr_per_view"]) == 2 and np.isfinite(rec["psnr_mean"])
+        assert os.path.getsize(out + "_view0.png") > 100
