@@ -83,6 +83,22 @@ size_t nerf_weight_gradient_workspace(int rows_out, int cols, long batch);
 int nerf_weight_gradient(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act, long batch,
                          float* d_dW, float* d_workspace, size_t workspace_bytes, int accumulate);
 
+/* nerf_weight_gradient for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): the split-K slabs go to a buffer of NERF_STATIC_SCRATCH_BYTES
+ * that is built into the library's device code (one copy per GPU, held until the process ends), so the
+ * call makes no hipMalloc / hipFree and uses no allocating library routine.  No counterpart in the
+ * reference.  Same plan, kernels and summation order as nerf_weight_gradient: identical bits.
+ * Returns 1, with a message on stderr, when nerf_weight_gradient_workspace(rows_out, cols, batch)
+ * exceeds NERF_STATIC_SCRATCH_BYTES (the reference's 512x512 and 512x150 gradients fit at any batch
+ * size).  The first call on a device resolves the buffer's address there (and loads the device code if
+ * nothing of the library has run on that device yet): make one call outside a capture first.  All
+ * calls on one GPU share the buffer, so calls that overlap on one GPU (two streams, two host threads)
+ * race; calls on one stream are ordered and safe.  Per-kernel timing (nerf_prof_enable) creates events
+ * and must stay off for the no-allocation guarantee to hold. */
+#define NERF_STATIC_SCRATCH_BYTES (64u << 20)
+int nerf_weight_gradient_static(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act, long batch,
+                                float* d_dW, int accumulate);
+
 /* ---- the same products with bf16 operands and fp32 accumulation (v_mfma_f32_32x32x16_bf16), for
  * the reduced-precision configuration; no counterpart in the reference (fp32 cuBLAS only).  bf16
  * values are passed as their 16-bit patterns. ----------------------------------------------- */

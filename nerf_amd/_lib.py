@@ -111,6 +111,7 @@ _SIGS = {
     "nerf_mlp_set_matrix_math": (C.c_int, [VP, C.c_int]),
     "nerf_weight_gradient_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_long]),
     "nerf_weight_gradient": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_long, VP, VP, C.c_size_t, C.c_int]),
+    "nerf_weight_gradient_static": (C.c_int, [VP, C.c_int, VP, C.c_int, C.c_int, C.c_long, VP, C.c_int]),
     "nerf_convert_bf16": (C.c_int, [VP, C.c_int, C.c_int, C.c_int, VP, C.c_int, C.c_int]),
     "nerf_gemm_bf16_nt": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, VP, VP]),
     "nerf_weight_gradient_bf16_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_long]),

@@ -10,12 +10,21 @@
 //   skinny_backward  EH = (E W2) .* swish'(Hpre) and dW2 += E^T swish(Hpre) in ONE pass over Hpre
 //                    (reads hidden*4 B, writes hidden*4 B per point)
 #include "mlp_internal.hpp"
+#include "../../include/nerf_amd.h"
 #include "../../include/nerf_spec.h"
 
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
+
 #pragma clang fp contract(off)
+
+// Slab space of nerf_weight_gradient_static, the entry point that allocates nothing: one copy per
+// GPU, held from the moment the code object is loaded until the process ends.  Host code never uses
+// this name as an address (here it is only a handle for hipGetSymbolAddress): the device address is
+// resolved once per device into g_scratch_ptr below.
+static __device__ __align__(256) float scratch[NERF_STATIC_SCRATCH_BYTES / sizeof(float)];
 
 namespace nerf {
 namespace {
@@ -626,6 +635,51 @@ extern "C" int nerf_weight_gradient_split(const float* d_err, int rows_out, cons
     if (workspace_bytes < nerf_weight_gradient_split_workspace(rows_out, cols, batch)) return NERF_ERR_ARG;
     nerf::weight_gradient(d_err, rows_out, d_act, cols, ld_act, batch, d_dW, d_workspace, accumulate,
                           nerf::MATH_SPLIT_BF16);
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+// ---- the weight gradient without any allocation ---------------------------------------------------
+namespace {
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices];  // device address of `scratch` on each GPU, filled on first use there
+std::mutex g_scratch_mutex;
+
+// Address of the current device's copy of `scratch`.  The first call on a device asks the runtime for
+// it (which loads the code object there if nothing of this library has run on that device yet).
+int static_scratch(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return NERF_ERR_HIP;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return NERF_ERR_HIP;
+        g_scratch_ptr[dev] = (float*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return NERF_OK;
+}
+}  // namespace
+
+// nerf_weight_gradient with the split-K slabs in the library's built-in buffer instead of a caller's
+// workspace: no hipMalloc / hipFree, nothing from an allocating library.  Same plan, same kernels,
+// same fixed summation order, hence the same bits as nerf_weight_gradient.  Every slab element the
+// reduce reads is written by the product first, so nothing has to be cleared between calls.
+extern "C" int nerf_weight_gradient_static(const float* d_err, int rows_out, const float* d_act, int cols, int ld_act,
+                                           long batch, float* d_dW, int accumulate) {
+    if (!d_err || !d_act || !d_dW || rows_out <= 0 || cols <= 0 || batch <= 0 || batch > 0x7fffffffL || ld_act < cols)
+        return NERF_ERR_ARG;
+    const size_t need = nerf_weight_gradient_workspace(rows_out, cols, batch);
+    if (need > (size_t)NERF_STATIC_SCRATCH_BYTES) {
+        fprintf(stderr,
+                "nerf_weight_gradient_static: a [%d x %d] gradient over %ld rows needs %zu bytes of slab space, the "
+                "built-in buffer holds %zu; use nerf_weight_gradient with a workspace of your own\n",
+                rows_out, cols, batch, need, (size_t)NERF_STATIC_SCRATCH_BYTES);
+        return NERF_ERR_ARG;
+    }
+    float* slabs = nullptr;
+    const int rc = static_scratch(&slabs);
+    if (rc != NERF_OK) return rc;
+    nerf::weight_gradient(d_err, rows_out, d_act, cols, ld_act, batch, d_dW, slabs, accumulate, nerf::MATH_EXACT);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
