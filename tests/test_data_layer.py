@@ -340,3 +340,28 @@ def test_decoder_is_byte_exact_on_every_bundled_image(lib):
         got = load_rgba(lib, path)
         assert got is not None and got.shape == want.shape, path
         assert np.array_equal(got, want), path
+
+
+SCENE_FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene")
+
+
+def test_scene_fixture_is_a_prefix_of_the_bundled_scene_and_loads(lib):
+    """tests/golden/scene: four views of the reference's dataset (the files travel with the
+    repository, unlike the reference checkout) through load_dataset, against PIL and the JSON"""
+    ds = lib.load_dataset(os.path.join(SCENE_FIXTURE, "transforms.json").encode(), SCENE_FIXTURE.encode(), 100)
+    assert ds and ds.contents.num_images == 4   # frames 4..99 are absent: skipped, data.c:229-239
+    meta = json.load(open(os.path.join(SCENE_FIXTURE, "transforms.json")))
+    for i in range(4):
+        im, cam = ds.contents.images[i].contents, ds.contents.cameras[i].contents
+        want = np.asarray(PIL_Image.open(os.path.join(SCENE_FIXTURE, f"r_{i}.png")).convert("RGBA"))
+        assert np.array_equal(np.ctypeslib.as_array(im.data, shape=want.shape), want)
+        m = np.array(meta["frames"][i]["transform_matrix"])
+        assert np.array_equal(np.array(cam.rotation[:], np.float32), m[:3, :3].astype(np.float32).reshape(-1))
+        assert np.array_equal(np.array(cam.position[:], np.float32), m[:3, 3].astype(np.float32))
+    lib.free_dataset(ds)
+    if os.path.exists(os.path.join(REF_DATA, "transforms.json")):
+        ref_meta = json.load(open(os.path.join(REF_DATA, "transforms.json")))
+        assert meta["frames"] == ref_meta["frames"][:4] and meta["camera_angle_x"] == ref_meta["camera_angle_x"]
+        for i in range(4):
+            assert open(os.path.join(SCENE_FIXTURE, f"r_{i}.png"), "rb").read() == \
+                open(os.path.join(REF_DATA, f"r_{i}.png"), "rb").read()
