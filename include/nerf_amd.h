@@ -297,6 +297,10 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
  *                                  a model trained with NERF_QUADRATURE_SPACING.
  * The products use each MLP's matrix arithmetic (nerf_mlp_set_matrix_math) in both functions. */
 enum { NERF_RENDER_FUSE_LINEAR_PAIR = 1, NERF_RENDER_SPACING_QUADRATURE = 2 };
+/* Both render functions keep their device buffers (one chunk's activations, the picture) between calls
+ * and rebuild them when the chunk size, the sample count or an MLP width changes; this frees them.
+ * The reference allocates and frees its render MLPs per picture (nerf.c:232-233,338-339). */
+void nerf_render_release(void);
 int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
                           unsigned char* host_rgb8, float* host_pixel, int options);

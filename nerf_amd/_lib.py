@@ -197,6 +197,7 @@ _SIGS = {
     "nerf_trainer_steps_done": (C.c_int, [VP]),
     "nerf_trainer_buffer": (VP, [VP, C.c_int]),
     "nerf_trainer_encoding_pitch": (C.c_int, [VP]),
+    "nerf_render_release": (None, []),
     "nerf_render_view": (C.c_int, [C.POINTER(MLP), C.POINTER(MLP), C.POINTER(Camera), C.c_int, C.c_int, C.c_int,
                                    C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, VP, VP]),
     "nerf_render_view_opts": (C.c_int, [C.POINTER(MLP), C.POINTER(MLP), C.POINTER(Camera), C.c_int, C.c_int, C.c_int,

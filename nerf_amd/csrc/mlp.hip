@@ -308,8 +308,15 @@ size_t mlp_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int ba
 // (ragged or unaligned operands) run on the exact kernels
 int mlp_gemm(const GemmArgs& g, int math) {
     if (math == MATH_SPLIT_BF16 && gemm_split_supported(g)) return gemm_split(g);
+    // split words are not floats: only the split-bf16 kernels can read them
+    if (g.operands_split) return NERF_ERR_ARG;
     return gemm_f32(g);
 }
+
+// May a step keep the operands of its large products as split words?  Hidden width `H` and batch
+// `N` are the contraction lengths of those products (whole 32-step K-tiles, gemm_split_supported)
+// and H is also an output width (the 256-wide tile of the split-word kernels needs more than 160).
+bool split_words_ok(int H, long N) { return H > 160 && H % 32 == 0 && N > 128 && N % 32 == 0; }
 
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T * Act[batch][cols]
 // Act rows are ld_act floats apart (ld_act >= cols; the trainer pads the 150-wide encoding to 160).
@@ -482,10 +489,14 @@ MLP* init_mlp(int input_dim, int hidden_dim, int output_dim, int batch_size, voi
     if (!mlp) return nullptr;
     const size_t n1 = (size_t)hidden_dim * input_dim, n2 = (size_t)output_dim * hidden_dim;
     float* h = (float*)malloc((n1 > n2 ? n1 : n2) * sizeof(float));
+    // copies go to the library's stream, behind mlp_create's memsets there (a synchronous copy on the
+    // null stream would be unordered with them when the caller's stream is a non-blocking one)
     host_init_weights(h, hidden_dim, input_dim);
-    NERF_HIP_CHECK(hipMemcpy(mlp->d_W1, h, n1 * 4, hipMemcpyHostToDevice));
+    NERF_HIP_CHECK(hipMemcpyAsync(mlp->d_W1, h, n1 * 4, hipMemcpyHostToDevice, stream()));
+    NERF_HIP_CHECK(hipStreamSynchronize(stream()));
     host_init_weights(h, output_dim, hidden_dim);
-    NERF_HIP_CHECK(hipMemcpy(mlp->d_W2, h, n2 * 4, hipMemcpyHostToDevice));
+    NERF_HIP_CHECK(hipMemcpyAsync(mlp->d_W2, h, n2 * 4, hipMemcpyHostToDevice, stream()));
+    NERF_HIP_CHECK(hipStreamSynchronize(stream()));
     free(h);
     return mlp;
 }
@@ -548,17 +559,18 @@ void save_mlp(MLP* mlp, const char* filename) {
     const size_t n1 = (size_t)mlp->hidden_dim * mlp->input_dim, n2 = (size_t)mlp->output_dim * mlp->hidden_dim;
     int32_t hdr[7] = {(int32_t)NERF_CKPT_MAGIC, NERF_CKPT_VERSION, mlp->input_dim, mlp->hidden_dim,
                       mlp->output_dim,          mlp->batch_size,   mlp->t};
-    fwrite(hdr, sizeof(hdr), 1, f);
+    bool ok = fwrite(hdr, sizeof(hdr), 1, f) == 1;
     float* h = (float*)malloc((n1 > n2 ? n1 : n2) * sizeof(float));
     const float* parts[6] = {mlp->d_W1, mlp->d_W2, mlp->d_W1_m, mlp->d_W1_v, mlp->d_W2_m, mlp->d_W2_v};
     const size_t counts[6] = {n1, n2, n1, n1, n2, n2};
-    NERF_HIP_CHECK(hipStreamSynchronize(stream()));
     for (int i = 0; i < 6; i++) {
-        NERF_HIP_CHECK(hipMemcpy(h, parts[i], counts[i] * 4, hipMemcpyDeviceToHost));
-        fwrite(h, 4, counts[i], f);
+        NERF_HIP_CHECK(hipMemcpyAsync(h, parts[i], counts[i] * 4, hipMemcpyDeviceToHost, stream()));
+        NERF_HIP_CHECK(hipStreamSynchronize(stream()));
+        ok = ok && fwrite(h, 4, counts[i], f) == counts[i];
     }
     free(h);
-    fclose(f);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { printf("Error: writing %s failed (disk full?)\n", filename); return; }
     printf("Model saved to %s\n", filename);
 }
 
@@ -604,7 +616,9 @@ MLP* load_mlp(const char* filename, int custom_batch_size, void* handle) {
             free(h); fclose(f); free_mlp(mlp);
             return nullptr;
         }
-        NERF_HIP_CHECK(hipMemcpy(parts[i], h, counts[i] * 4, hipMemcpyHostToDevice));
+        // on the library's stream, behind mlp_create's memsets of the same buffers
+        NERF_HIP_CHECK(hipMemcpyAsync(parts[i], h, counts[i] * 4, hipMemcpyHostToDevice, stream()));
+        NERF_HIP_CHECK(hipStreamSynchronize(stream()));
     }
     free(h);
     fclose(f);

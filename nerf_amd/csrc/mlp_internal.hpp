@@ -29,6 +29,8 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
 // fused linear pair).  `math`: MATH_EXACT or MATH_SPLIT_BF16 (shapes the split kernels do not take
 // run exact).
 int mlp_gemm(const GemmArgs& g, int math);
+// whether a step with hidden width H over N points may keep its large products' operands as split words
+bool split_words_ok(int H, long N);
 bool skinny_ok(int hidden, int out_dim);
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]; workspace >= wgrad_slab_bytes(...)
 // operands_split: Err and Act hold split words (common.hpp); needs math == MATH_SPLIT_BF16

@@ -224,8 +224,10 @@ int main(int argc, char** argv) {
     }
     if (o.resume[0]) {
         printf("Loading existing models:\n  Model 1: %s\n  Model 2: %s\n", o.resume[0], o.resume[1]);
-        MLP* l1 = load_mlp(o.resume[0], points, NULL);
-        MLP* l2 = load_mlp(o.resume[1], points, NULL);
+        /* the device-side step only copies weights and moments out of the loaded MLPs: a batch size
+         * of 1 keeps their activation buffers (8 GB at 4096 x 128) from being allocated for nothing */
+        MLP* l1 = load_mlp(o.resume[0], o.fused ? 1 : points, NULL);
+        MLP* l2 = load_mlp(o.resume[1], o.fused ? 1 : points, NULL);
         if (!l1 || !l2) {
             fprintf(stderr, "Failed to load one or both models\n");
             if (l1) free_mlp(l1);

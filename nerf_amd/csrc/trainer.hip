@@ -303,13 +303,15 @@ NerfTrainer* nerf_trainer_create(const NerfTrainerConfig* cfg, float* d_param_ar
     dalloc(&tr->d_m, tr->n_params);
     dalloc(&tr->d_v, tr->n_params);
     tr->pe_ld = ((tr->pe_dim + 31) / 32) * 32;
-    // Split words need the large tile shapes of the split-bf16 kernels in all five big products.
-    // NERF_SPLIT_IN_REGISTERS=1 (a diagnostic switch) keeps fp32 operands and splits inside the kernels:
-    // bit-identical results, slower.
+    // Split words need the split-bf16 kernels, in their large tile shapes, for all five big products:
+    // contractions over the hidden width (K = H) and over the batch (K = N) in whole 32-step K-tiles,
+    // and outputs wide enough for the 256-wide (or, for the encoding's weight gradient, 160-wide) tile.
+    // Any other shape keeps fp32 operands and splits inside the kernels (or runs exact where those do
+    // not apply).  NERF_SPLIT_IN_REGISTERS=1 (a diagnostic switch) forces that: bit-identical, slower.
     {
         const char* env = getenv("NERF_SPLIT_IN_REGISTERS");
         tr->words = cfg->precision == NERF_PRECISION_SPLIT_BF16 && cfg->fuse_linear_pair && !(env && env[0] == '1') &&
-                    H > 160 && H % 4 == 0 && N > 128 && (tr->pe_dim > 160 || wgrad_tile_n(tr->pe_dim) == 160);
+                    split_words_ok(H, N) && (tr->pe_dim > 160 || wgrad_tile_n(tr->pe_dim) == 160);
     }
     if (!bf16) {
         dalloc(&tr->d_pe, (size_t)N * tr->pe_ld);
@@ -544,6 +546,72 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
                                  dir_enc_l, rays_per_chunk, host_rgb8, host_pixel, 0);
 }
 
+// Device buffers of the renderer, kept between calls (a trainer that renders every few thousand
+// steps would otherwise allocate and free gigabytes per picture): forward-only views of the two MLPs
+// for one chunk of rays, the chunk's encoding, the re-pitched layer-1 weights, the fused pair's
+// matrix and the picture.  Rebuilt when the chunk size or a width changes; nerf_render_release()
+// frees them.
+namespace {
+struct RenderCache {
+    int N, in1, H1, mid, H2, out2, pe_ld;
+    size_t pixels;  // capacity of d_pixel / d_rgb8 in pixels
+    MLP *r1, *r2;
+    float *d_pe, *d_w1p, *d_wc, *d_pixel;
+    unsigned char* d_rgb8;
+};
+RenderCache g_render = {};
+
+void render_cache_free() {
+    if (g_render.r1) free_mlp(g_render.r1);
+    if (g_render.r2) free_mlp(g_render.r2);
+    hipFree(g_render.d_pe); hipFree(g_render.d_w1p); hipFree(g_render.d_wc); hipFree(g_render.d_pixel);
+    hipFree(g_render.d_rgb8);
+    memset(&g_render, 0, sizeof(g_render));
+}
+
+// makes g_render fit this call; NERF_OK or NERF_ERR_HIP (then the cache is empty)
+int render_cache_prepare(const MLP* mlp1, const MLP* mlp2, int N, int pe_ld, size_t total) {
+    RenderCache& c = g_render;
+    const bool same = c.r1 && c.N == N && c.in1 == mlp1->input_dim && c.H1 == mlp1->hidden_dim &&
+                      c.mid == mlp1->output_dim && c.H2 == mlp2->hidden_dim && c.out2 == mlp2->output_dim &&
+                      c.pe_ld == pe_ld;
+    if (!same) {
+        render_cache_free();
+        c.N = N; c.in1 = mlp1->input_dim; c.H1 = mlp1->hidden_dim; c.mid = mlp1->output_dim;
+        c.H2 = mlp2->hidden_dim; c.out2 = mlp2->output_dim; c.pe_ld = pe_ld;
+        // forward-only views: the weight pointers are set per call (the reference clones the weights
+        // into batch-128 MLPs instead, nerf.c:232-243)
+        c.r1 = mlp_create(c.in1, c.H1, c.mid, N, nullptr, mlp1->d_W1, mlp1->d_W2, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, MLP_FORWARD_ONLY);
+        c.r2 = mlp_create(c.mid, c.H2, c.out2, N, nullptr, mlp2->d_W1, mlp2->d_W2, nullptr, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, MLP_FORWARD_ONLY);
+        bool ok = c.r1 && c.r2 && hipMalloc((void**)&c.d_pe, (size_t)N * pe_ld * 4) == hipSuccess &&
+                  hipMalloc((void**)&c.d_w1p, (size_t)c.H1 * pe_ld * 4) == hipSuccess &&
+                  hipMalloc((void**)&c.d_wc, (size_t)c.H2 * c.H1 * 4) == hipSuccess;
+        // the row tails of the encoding stay zero from here on: the encoder writes pe_dim floats per row
+        ok = ok && hipMemsetAsync(c.d_pe, 0, (size_t)N * pe_ld * 4, stream()) == hipSuccess;
+        if (!ok) { render_cache_free(); return NERF_ERR_HIP; }
+    }
+    if (c.pixels < total) {
+        hipFree(c.d_pixel); hipFree(c.d_rgb8);
+        c.d_pixel = nullptr; c.d_rgb8 = nullptr; c.pixels = 0;
+        if (hipMalloc((void**)&c.d_pixel, total * 3 * 4) != hipSuccess ||
+            hipMalloc((void**)&c.d_rgb8, total * 3) != hipSuccess) {
+            render_cache_free();
+            return NERF_ERR_HIP;
+        }
+        c.pixels = total;
+    }
+    c.r1->d_W1 = mlp1->d_W1; c.r1->d_W2 = mlp1->d_W2;
+    c.r2->d_W1 = mlp2->d_W1; c.r2->d_W2 = mlp2->d_W2;
+    c.r1->matrix_math = mlp1->matrix_math;  // render with the arithmetic the MLPs train with
+    c.r2->matrix_math = mlp2->matrix_math;
+    return NERF_OK;
+}
+}  // namespace
+
+void nerf_render_release(void) { render_cache_free(); }
+
 int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
                           unsigned char* host_rgb8, float* host_pixel, int options) {
@@ -555,54 +623,39 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
     if (fuse_linear_pair && !skinny_ok(mlp2->hidden_dim, mlp2->output_dim)) return NERF_ERR_ARG;
     const int pe_dim = NERF_PE_DIM3(pos_enc_l) + NERF_PE_DIM3(dir_enc_l);
     if (mlp1->input_dim != pe_dim || mlp2->input_dim != mlp1->output_dim || mlp2->output_dim < 4) return NERF_ERR_ARG;
+    if ((long long)render_w * render_h > 0x7fffffffLL / 3) return NERF_ERR_ARG;  // pixel indices are ints
     const int total = render_w * render_h;
     if (rays_per_chunk <= 0) rays_per_chunk = 4096;
     if (rays_per_chunk > total) rays_per_chunk = total;
+    if ((long long)rays_per_chunk * num_samples > 0x7fffffffLL) return NERF_ERR_ARG;  // as nerf_trainer_create
     const int N = rays_per_chunk * num_samples;
-    // forward-only views of the two MLPs sharing the trained weights (the reference clones the
-    // weights into batch-128 MLPs instead, nerf.c:232-243)
-    MLP* r1 = mlp_create(mlp1->input_dim, mlp1->hidden_dim, mlp1->output_dim, N, nullptr, mlp1->d_W1, mlp1->d_W2,
-                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
-    MLP* r2 = mlp_create(mlp2->input_dim, mlp2->hidden_dim, mlp2->output_dim, N, nullptr, mlp2->d_W1, mlp2->d_W2,
-                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
-    if (r1 && r2) {  // render with the arithmetic the MLPs train with
-        r1->matrix_math = mlp1->matrix_math;
-        r2->matrix_math = mlp2->matrix_math;
-    }
     const int pe_ld = ((pe_dim + 31) / 32) * 32;  // pitched like the trainer's encoding (zero row tails)
-    float *d_pe = nullptr, *d_pixel = nullptr, *d_w1p = nullptr, *d_wc = nullptr;
-    unsigned char* d_rgb8 = nullptr;
-    int rc = NERF_OK;
+    int rc = render_cache_prepare(mlp1, mlp2, N, pe_ld, (size_t)total);
+    if (rc != NERF_OK) return rc;
+    MLP *r1 = g_render.r1, *r2 = g_render.r2;
+    float *d_pe = g_render.d_pe, *d_pixel = g_render.d_pixel, *d_w1p = g_render.d_w1p, *d_wc = g_render.d_wc;
+    unsigned char* d_rgb8 = g_render.d_rgb8;
     const int H1 = mlp1->hidden_dim, H2 = mlp2->hidden_dim, Mid = mlp1->output_dim;
-    // split-bf16 + fused pair: the two products read split words (see NerfTrainer::words); both fit
-    // the large tile shape when the widths and the chunk allow
-    const bool words = fuse_linear_pair && mlp1->matrix_math == MATH_SPLIT_BF16 && H1 > 160 && H2 > 160 &&
-                       H1 % 4 == 0 && H2 % 4 == 0 && N > 128 && !(getenv("NERF_SPLIT_IN_REGISTERS") &&
-                                                                 getenv("NERF_SPLIT_IN_REGISTERS")[0] == '1');
-    if (!r1 || !r2 || hipMalloc((void**)&d_pe, (size_t)N * pe_ld * 4) != hipSuccess ||
-        (fuse_linear_pair && hipMalloc((void**)&d_wc, (size_t)H2 * H1 * 4) != hipSuccess) ||
-        ((pe_ld != pe_dim || words) && hipMalloc((void**)&d_w1p, (size_t)mlp1->hidden_dim * pe_ld * 4) != hipSuccess) ||
-        hipMalloc((void**)&d_pixel, (size_t)total * 3 * 4) != hipSuccess ||
-        hipMalloc((void**)&d_rgb8, (size_t)total * 3) != hipSuccess)
-        rc = NERF_ERR_HIP;
+    // split-bf16 + fused pair: the two products read split words (see NerfTrainer::words) when both fit
+    // the split-word kernels (whole K-tiles over H1, wide outputs)
+    const bool words = fuse_linear_pair && mlp1->matrix_math == MATH_SPLIT_BF16 && split_words_ok(H1, N) &&
+                       split_words_ok(H2, N) && !(getenv("NERF_SPLIT_IN_REGISTERS") &&
+                                                  getenv("NERF_SPLIT_IN_REGISTERS")[0] == '1');
     PitchedInput in = {d_pe, pe_ld, mlp1->d_W1};
-    if (rc == NERF_OK) {
-        NERF_HIP_CHECK(hipMemsetAsync(d_pe, 0, (size_t)N * pe_ld * 4, stream()));
-        if (d_w1p) {
-            NERF_HIP_CHECK(hipMemsetAsync(d_w1p, 0, (size_t)mlp1->hidden_dim * pe_ld * 4, stream()));
-            NERF_HIP_CHECK(hipMemcpy2DAsync(d_w1p, (size_t)pe_ld * 4, mlp1->d_W1, (size_t)pe_dim * 4, (size_t)pe_dim * 4,
-                                            mlp1->hidden_dim, hipMemcpyDeviceToDevice, stream()));
-            in.W1 = d_w1p;
-            if (words) to_split_words(d_w1p, d_w1p, (size_t)mlp1->hidden_dim * pe_ld);
-        }
-        if (fuse_linear_pair) {  // Wc = W1b W2a, once per view (see after_forward_fused)
-            GemmArgs g = {};
-            g.A = mlp2->d_W1; g.lda = Mid; g.a_kc = 1;
-            g.B = mlp1->d_W2; g.ldb = H1; g.b_kc = 0;
-            g.C = d_wc; g.ldc = H1; g.M = H2; g.N = H1; g.K = Mid; g.epilogue = EPI_STORE;
-            g.c_split = words;
-            rc = gemm_f32(g);
-        }
+    if (pe_ld != pe_dim || words) {
+        NERF_HIP_CHECK(hipMemsetAsync(d_w1p, 0, (size_t)H1 * pe_ld * 4, stream()));
+        NERF_HIP_CHECK(hipMemcpy2DAsync(d_w1p, (size_t)pe_ld * 4, mlp1->d_W1, (size_t)pe_dim * 4, (size_t)pe_dim * 4, H1,
+                                        hipMemcpyDeviceToDevice, stream()));
+        in.W1 = d_w1p;
+        if (words) to_split_words(d_w1p, d_w1p, (size_t)H1 * pe_ld);
+    }
+    if (fuse_linear_pair) {  // Wc = W1b W2a, once per view (see after_forward_fused)
+        GemmArgs g = {};
+        g.A = mlp2->d_W1; g.lda = Mid; g.a_kc = 1;
+        g.B = mlp1->d_W2; g.ldb = H1; g.b_kc = 0;
+        g.C = d_wc; g.ldc = H1; g.M = H2; g.N = H1; g.K = Mid; g.epilogue = EPI_STORE;
+        g.c_split = words;
+        rc = gemm_f32(g);
     }
     for (int first = 0; rc == NERF_OK && first < total; first += rays_per_chunk) {
         const int count = (total - first) < rays_per_chunk ? (total - first) : rays_per_chunk;
@@ -652,9 +705,6 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
         if (rc == NERF_OK && host_rgb8) rc = nerf_memcpy_d2h(host_rgb8, d_rgb8, (size_t)total * 3);
         if (rc == NERF_OK && hipStreamSynchronize(stream()) != hipSuccess) rc = NERF_ERR_HIP;
     }
-    if (r1) free_mlp(r1);
-    if (r2) free_mlp(r2);
-    hipFree(d_pe); hipFree(d_pixel); hipFree(d_rgb8); hipFree(d_w1p); hipFree(d_wc);
     return rc;
 }
 

@@ -196,3 +196,54 @@ def test_render_with_split_words_is_bit_identical(gpu, oracle_fast, monkeypatch)
     _, pix_e = q.tr.render_view(cam, 24, 16, rays_per_chunk=96)
     np.testing.assert_allclose(pix_w, pix_e, rtol=0, atol=1e-4)
     assert not np.array_equal(pix_w, pix_e)
+
+
+def test_split_bf16_with_the_fused_pair_at_shapes_that_cannot_hold_split_words(gpu, oracle_fast):
+    """Batches that are not whole 32-row K-tiles (5 rays x 100 samples) and widths the split-word
+    kernels do not take: the step keeps fp32 operands (splitting inside the kernels where they apply,
+    exact products elsewhere) instead of handing split words to a kernel that cannot read them."""
+    from nerf_amd.api import DeviceArray
+    for (R, S, Lp, Ld, hidden, inter) in [(5, 100, 16, 8, 512, 512), (3, 50, 16, 8, 256, 512), (8, 64, 4, 2, 128, 64)]:
+        p = Pair(gpu, oracle_fast, R, S, Lp, Ld, hidden, inter, precision=2, fuse_linear_pair=1)
+        idx = p.indices(R * S + 1)
+        p.tr.forward_backward(p.dds, DeviceArray.from_numpy(idx))
+        _, _, o_loss = p.oracle_step(idx, literal=False)
+        grads, sse = p.tr.get_grads()
+        assert sse == pytest.approx(o_loss, rel=REL)
+        og = p.oracle_grads()
+        for (off, shape) in p.tr.param_slices():
+            n = shape[0] * shape[1]
+            norm_close(grads[off:off + n], og[off:off + n], 2e-4)
+        p.tr.destroy()
+
+
+def test_render_with_a_first_hidden_width_that_is_not_a_whole_k_tile(gpu):
+    """The renderer takes any two MLPs: with split-bf16 products, the fused pair and a first hidden
+    width of 200 (not a multiple of 32) the pair's product cannot run on the split kernels, so the
+    operands must stay floats.  The picture equals the exact-fp32 one to the product tolerance."""
+    import ctypes as C
+    from nerf_amd._lib import lib
+    from nerf_amd.api import make_camera
+    from conftest import make_scene
+    libc = C.CDLL("libc.so.6")
+    libc.srand(77)
+    m1 = lib.init_mlp(150, 200, 512, 64, None)
+    m2 = lib.init_mlp(512, 512, 4, 64, None)
+    assert m1 and m2
+    cams, _ = make_scene(1, 40, 30)
+    cam = make_camera(*cams[0])
+
+    def render(options, math):
+        assert lib.nerf_mlp_set_matrix_math(m1, math) == 0 and lib.nerf_mlp_set_matrix_math(m2, math) == 0
+        pix = np.empty((16, 24, 3), np.float32)
+        rc = lib.nerf_render_view_opts(m1, m2, C.byref(cam), 24, 16, 128, 2.0, 6.0, 16, 8, 192, None, pix.ctypes.data, options)
+        assert rc == 0
+        return pix
+    exact = render(0, 0)
+    fused_split = render(1, 1)
+    fused_exact = render(1, 0)
+    assert np.isfinite(exact).all() and exact.std() > 0
+    np.testing.assert_allclose(fused_exact, exact, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(fused_split, exact, rtol=0, atol=1e-4)
+    lib.free_mlp(m1)
+    lib.free_mlp(m2)

@@ -156,3 +156,39 @@ def test_dataset_resolution_render_full_size(gpu, oracle_fast):
     oracle_fast.free_step(buf)
     oracle_fast.free_mlp(m1)
     oracle_fast.free_mlp(m2)
+
+
+def test_render_buffers_are_kept_between_calls_and_released_on_request(gpu, oracle):
+    """the renderer allocates once per (chunk, widths) and reuses: repeated renders give the same
+    picture, device memory does not grow call over call, a different chunk size or picture size
+    rebuilds, nerf_render_release gives the memory back, and oversized requests are refused"""
+    torch = pytest.importorskip("torch")
+    from nerf_amd._lib import lib
+    from nerf_amd.api import make_camera
+    tr, parts = setup_pair(gpu, oracle, 64)
+    cams, _ = make_scene(1, 40, 30)
+    cam = make_camera(*cams[0])
+    torch.cuda.init()
+    lib.nerf_render_release()
+    lib.nerf_stream_synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    first = tr.render_view(cam, 64, 48, rays_per_chunk=1024)[1]
+    free1, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        again = tr.render_view(cam, 64, 48, rays_per_chunk=1024)[1]
+        assert np.array_equal(again, first)
+    free2, _ = torch.cuda.mem_get_info()
+    assert free2 == free1, "a repeated render must not allocate"
+    other_chunk = tr.render_view(cam, 64, 48, rays_per_chunk=500)[1]      # ragged last chunk, rebuilt buffers
+    assert np.array_equal(other_chunk, first)
+    small = tr.render_view(cam, 16, 12, rays_per_chunk=500)[1]            # smaller picture, same buffers
+    ref = oracle_render(oracle, parts, cams[0], 16, 12, 64, 6, 3, 128, 64)
+    np.testing.assert_allclose(small, ref, rtol=REL, atol=PIX_ATOL)
+    lib.nerf_render_release()
+    lib.nerf_stream_synchronize()
+    free3, _ = torch.cuda.mem_get_info()
+    assert free0 - free3 < 8 * 1024 * 1024, f"{(free0 - free3) / 2**20:.0f} MiB not returned"
+    # sizes whose products leave the int range are refused, not wrapped
+    m1, m2 = lib.nerf_trainer_mlp(tr.handle, 0), lib.nerf_trainer_mlp(tr.handle, 1)
+    assert lib.nerf_render_view_opts(m1, m2, C.byref(cam), 40000, 40000, 64, 2.0, 6.0, 6, 3, 4096, None, None, 0) == 1
+    assert lib.nerf_render_view_opts(m1, m2, C.byref(cam), 8192, 8192, 1024, 2.0, 6.0, 6, 3, 8192 * 8192, None, None, 0) == 1
