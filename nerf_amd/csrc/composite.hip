@@ -8,16 +8,21 @@
 // One 64-lane wavefront owns one ray.  Lane l holds the SPL = ceil(S/64) consecutive samples
 // [l*SPL, (l+1)*SPL) in registers, so a ray's S samples are read with one coalesced sweep.
 //   forward : transmittance = exclusive product scan of (1 - alpha) across the wavefront
-//             (lane-local running product, then a 6-step shuffle scan of the lane products);
+//             (lane-local running product, then a 6-step __shfl_up scan of the lane products);
 //             a sample contributes iff the transmittance in front of it is >= T_STOP, which is
 //             the reference's "accumulate, then break when T < 0.01" rule (T never increases);
-//             the pixel sum is a butterfly reduction.
+//             the pixel sum is a butterfly reduction.  The scan associates the product differently
+//             from the reference's left-to-right loop (nerf.c:42), so a transmittance within a few
+//             ulps of 0.01 could fall on the other side of the stop: a ray on which any scanned
+//             value lies inside the provable error band around T_STOP (guard_band(), about one ray
+//             in 10^5) is multiplied up again in the reference's order and decided by that.
 //   backward: the reference's O(S^3) density-gradient loop equals the reverse recurrence
 //             R_{S-1} = 0, R_s = (1-a_s)(a_{s+1} q_{s+1} + R_{s+1}), G_s = da_s (T_s q_s - R_s)
 //             with q_s = sum_c err_c rgb_{s,c}; it is evaluated as a reverse scan under
 //             composition of the affine maps x -> (1-a_s) x + (1-a_s) a_{s+1} q_{s+1}.
-//             No early stop here (nerf.c:77-87 has none).
-// Both kernels are HBM-bound: 16 B read (+16 B written) per sample.
+//             No early stop here (nerf.c:77-87 has none), hence no decision and no band.
+// Both kernels move 16 B per sample in (+16 B out for the gradient); what they cost beyond that is
+// the exponential behind each alpha and the three sigmoids per sample.
 //
 // SPACING = true is an opt-in quadrature that is NOT the reference's: alpha_s = 1 - exp(-dens_s delta_s)
 // with the true spacing delta_s = t_{s+1} - t_s of the (possibly jittered) sample depths,
@@ -32,32 +37,90 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigmoid_ref(float x) { return 1.0f / (1.0f + expf(-x)); }
+// e^x to about 1.5 ulp: x log2(e) split into a rounded integer and a remainder carried in two
+// pieces, the hardware exp2 on the remainder, ldexp for the integer.  Overflow and underflow come out
+// of the ldexp as inf and 0; no range tests.
+__device__ __forceinline__ float expf_fast(float x) {
+    const float t = x * 1.44269502e+00f;
+    const float k = __builtin_rintf(t);
+    float f = fmaf(x, 1.44269502e+00f, -k);  // the rounding error of t is recovered by the fma
+    f = fmaf(x, 1.92596299e-08f, f);         // log2(e) - float(log2(e))
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)k);
+}
 
-// expf rounded correctly (via the double-precision exp): alpha = 1 - expf(-0.01 * density) cancels
-// for small densities, so a one-ulp difference in expf moves alpha by 6e-8 whatever its size --
-// up to 1e-3 RELATIVE on the weights of a thin medium.  The correctly rounded value is what a host
-// libm returns, and these kernels have the double-precision throughput to spare (HBM-bound).
-__device__ __forceinline__ float expf_cr(float x) { return (float)exp((double)x); }
+// 1 / (1 + expf(-x)) (nerf.c:15-17).  The division is a reciprocal and one Newton step (within an ulp
+// of the IEEE quotient; the denominator is >= 1) instead of the ten-instruction IEEE sequence; the
+// exponent is capped at 88 so that the denominator stays finite (sigmoid(-88) = 6e-39 either way).
+// Absolute error below 1e-7.
+__device__ __forceinline__ float sigmoid_ref(float x) {
+    const float d = 1.0f + expf_fast(fminf(-x, 88.0f));
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
 
-// exclusive product scan over the 64 lanes of a wavefront
+// expf rounded correctly, for x <= 0: alpha = 1 - expf(-0.01 * density) cancels for small densities,
+// so a one-ulp difference in expf moves alpha by 6e-8 whatever its size -- up to 1e-3 RELATIVE on the
+// weights of a thin medium.  The correctly rounded value is what a host libm returns.  Evaluated in
+// double precision: x = k ln2 + r with |r| <= ln2/2, a degree-10 Taylor polynomial of exp(r)
+// (truncation 2e-13 relative, so the float rounding differs from the exact one about once in 10^5
+// arguments), scaled by 2^k and rounded to float once.  18 double-precision instructions, half of
+// what the general-purpose exp() spends on ranges that cannot occur here.
+__device__ __forceinline__ float expf_cr(float xf) {
+    const double x = (double)fmaxf(xf, -104.0f);  // exp(-104) < 2^-150 rounds to zero: so does everything below (and -inf)
+    const double kd = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(kd, -6.93147180369123816490e-01, x);  // ln2 split so that kd * hi is exact
+    r = __builtin_fma(kd, -1.90821492927058770002e-10, r);
+    double p = 2.7557319223985890653e-07;          // 1/10!
+    p = __builtin_fma(p, r, 2.7557319223985892511e-06);  // 1/9!
+    p = __builtin_fma(p, r, 2.4801587301587301566e-05);  // 1/8!
+    p = __builtin_fma(p, r, 1.9841269841269841253e-04);  // 1/7!
+    p = __builtin_fma(p, r, 1.3888888888888889419e-03);  // 1/6!
+    p = __builtin_fma(p, r, 8.3333333333333332177e-03);  // 1/5!
+    p = __builtin_fma(p, r, 4.1666666666666664354e-02);  // 1/4!
+    p = __builtin_fma(p, r, 1.6666666666666665741e-01);  // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return (float)__builtin_ldexp(p, (int)kd);
+}
+
+// Half-width of the band around T_STOP inside which a scanned transmittance does not settle the
+// reference's stop decision.  Any way of multiplying up p factors in fp32 takes p - 1 roundings of
+// relative size <= 2^-24 each, so two differently associated products of the same <= S factors differ
+// by less than 2 S 2^-24 relative; 1.5 covers the second-order terms.  Outside the band the scanned
+// value and the reference's running product lie on the same side of T_STOP.
+__device__ __forceinline__ float guard_band(int S) { return NERF_T_STOP * (3.0f * (float)S) * 5.9604645e-8f; }
+
+// Lane-crossing through the DPP path of the vector ALU (no LDS traffic, no index arithmetic): lane l
+// receives src from the lane the control word names, or keeps `old` when that lane lies outside its
+// row of 16 (or outside the masked rows / banks).
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 CTRL, ROW_MASK, BANK_MASK, false));
+}
+enum { DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141,
+       DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_QUAD_1032 = 0xb1, DPP_QUAD_2301 = 0x4e };
+
+// exclusive product scan over the 64 lanes of a wavefront: inclusive scans inside the four rows of
+// 16 lanes, each row's total passed on to the rows after it, then one lane to the right
 __device__ __forceinline__ float wave_exclusive_product(float x, int lane) {
-    float incl = x;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float y = __shfl_up(incl, d, 64);
-        if (lane >= d) incl *= y;
-    }
-    const float ex = __shfl_up(incl, 1, 64);
-    return lane == 0 ? 1.0f : ex;
+    (void)lane;
+    float v = x;
+    v *= dpp<DPP_ROW_SHR + 1>(1.0f, v);
+    v *= dpp<DPP_ROW_SHR + 2>(1.0f, v);
+    v *= dpp<DPP_ROW_SHR + 4>(1.0f, v);
+    v *= dpp<DPP_ROW_SHR + 8>(1.0f, v);
+    v *= dpp<DPP_ROW_BCAST15, 0xa>(1.0f, v);  // last lane of rows 0 and 2 into every lane of rows 1 and 3
+    v *= dpp<DPP_ROW_BCAST31, 0xc>(1.0f, v);  // lane 31 into every lane of rows 2 and 3
+    return dpp<DPP_WAVE_SHR1>(1.0f, v);       // lane 0 keeps 1
 }
 
 // Transmittance in front of this lane's first sample, multiplied up in the REFERENCE's order: one
-// running product over all samples, left to right (nerf.c:42, nerf.c:85).  Every lane walks the same
-// chain (the factors come by wave-uniform lane reads), so the value each lane keeps is bit for bit
-// what a sequential loop holds at that sample -- and with it the early-stop decision (nerf.c:43) is
-// the sequential loop's, not that of a differently associated scan.  S multiplies per ray: nothing
-// beside the 16 bytes per sample these kernels move.
+// running product over all samples, left to right (nerf.c:42).  Every lane walks the same chain (the
+// factors come by wave-uniform lane reads), so the value each lane keeps is bit for bit what a
+// sequential loop holds at that sample -- and with it the early-stop decision (nerf.c:43).  S
+// dependent multiplies: only the rare rays inside the guard band take this path.
 template <int SPL>
 __device__ __forceinline__ float sequential_transmittance(const float (&alpha)[SPL], int lane) {
     float T = 1.0f, mine = 1.0f;
@@ -69,10 +132,16 @@ __device__ __forceinline__ float sequential_transmittance(const float (&alpha)[S
     return mine;
 }
 
+// sum over the wavefront, returned in every lane: butterflies inside each row of 16, row totals
+// chained into lane 63, one scalar read
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-    return x;
+    x += dpp<DPP_QUAD_1032>(0.0f, x);
+    x += dpp<DPP_QUAD_2301>(0.0f, x);
+    x += dpp<DPP_ROW_HALF_MIRROR>(0.0f, x);
+    x += dpp<DPP_ROW_MIRROR>(0.0f, x);
+    x += dpp<DPP_ROW_BCAST15, 0xa>(0.0f, x);
+    x += dpp<DPP_ROW_BCAST31, 0xc>(0.0f, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 63));
 }
 
 // exclusive suffix sum over the 64 lanes: lane l receives sum of x over lanes > l
@@ -98,24 +167,27 @@ __device__ __forceinline__ float sample_spacing(int s, int S, float near_plane, 
     return __fsub_rn(sample_depth_of(s + 1, S, near_plane, far_plane, off), sample_depth_of(s, S, near_plane, far_plane, off));
 }
 
-// Loads one sample's density and colour.  RAW: from the MLP's raw output row (activation applied
-// here: ReLU on channel 0, sigmoid on 1..3, nerf.c:13-17).  Otherwise from dens[] / rgb[].
+// One sample as it lies in memory: (density, r, g, b).  RAW: the MLP's raw output row; otherwise
+// dens[] / rgb[].  The loads of all of a lane's samples are issued before anything is computed on them.
 template <bool RAW>
-__device__ __forceinline__ void load_sample(const float* __restrict__ raw, int out_dim, const float* __restrict__ dens,
-                                            const float* __restrict__ rgb, size_t p, float& d, float (&c)[3]) {
+__device__ __forceinline__ f32x4 fetch_sample(const float* __restrict__ raw, int out_dim, const float* __restrict__ dens,
+                                              const float* __restrict__ rgb, size_t p) {
     if (RAW) {
-        if (out_dim == 4) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(raw + p * 4);
-            d = fmaxf(0.0f, y[0]);
-            c[0] = sigmoid_ref(y[1]); c[1] = sigmoid_ref(y[2]); c[2] = sigmoid_ref(y[3]);
-        } else {
-            const float* y = raw + p * out_dim;
-            d = fmaxf(0.0f, y[0]);
-            c[0] = sigmoid_ref(y[1]); c[1] = sigmoid_ref(y[2]); c[2] = sigmoid_ref(y[3]);
-        }
+        if (out_dim == 4) return *reinterpret_cast<const f32x4*>(raw + p * 4);
+        const float* y = raw + p * out_dim;
+        return f32x4{y[0], y[1], y[2], y[3]};
+    }
+    return f32x4{dens[p], rgb[p * 3 + 0], rgb[p * 3 + 1], rgb[p * 3 + 2]};
+}
+// RAW: the output activation (ReLU on channel 0, sigmoid on 1..3, nerf.c:13-17)
+template <bool RAW>
+__device__ __forceinline__ void activate_sample(const f32x4 y, float& d, float (&c)[3]) {
+    if (RAW) {
+        d = fmaxf(0.0f, y[0]);
+        c[0] = sigmoid_ref(y[1]); c[1] = sigmoid_ref(y[2]); c[2] = sigmoid_ref(y[3]);
     } else {
-        d = dens[p];
-        c[0] = rgb[p * 3 + 0]; c[1] = rgb[p * 3 + 1]; c[2] = rgb[p * 3 + 2];
+        d = y[0];
+        c[0] = y[1]; c[1] = y[2]; c[2] = y[3];
     }
 }
 
@@ -133,31 +205,48 @@ __global__ __launch_bounds__(256) void composite_forward_kernel(
     const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= R) return;  // whole wavefront leaves together
 
+    // samples past the end of the ray re-read the last one (a valid address, no branch around the
+    // load) and get alpha = 0, which takes them out of every sum and product below
+    f32x4 y[SPL];
+#pragma unroll
+    for (int i = 0; i < SPL; i++) {
+        const int s = min(lane * SPL + i, S - 1);
+        y[i] = fetch_sample<RAW>(raw, out_dim, dens_in, rgb_in, (size_t)ray * S + s);
+    }
     float alpha[SPL], col[SPL][3];
     float local = 1.0f;
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
         const int s = lane * SPL + i;
-        alpha[i] = 0.0f;
-        col[i][0] = col[i][1] = col[i][2] = 0.0f;
-        if (s < S) {
+        float d;
+        activate_sample<RAW>(y[i], d, col[i]);
+        if (RAW && dens_out && s < S) {
             const size_t p = (size_t)ray * S + s;
-            float d;
-            load_sample<RAW>(raw, out_dim, dens_in, rgb_in, p, d, col[i]);
-            if (RAW && dens_out) {
-                dens_out[p] = d;
-                rgb_out[p * 3 + 0] = col[i][0]; rgb_out[p * 3 + 1] = col[i][1]; rgb_out[p * 3 + 2] = col[i][2];
-            }
-            if (SPACING) {
-                const float* off = sp.offsets ? sp.offsets + (size_t)ray * S : nullptr;
-                alpha[i] = 1.0f - expf_cr(-d * sample_spacing(s, S, sp.near_plane, sp.far_plane, off));
-            } else {
-                alpha[i] = 1.0f - expf_cr(-d * NERF_DELTA);  // nerf.c:35
-            }
+            dens_out[p] = d;
+            rgb_out[p * 3 + 0] = col[i][0]; rgb_out[p * 3 + 1] = col[i][1]; rgb_out[p * 3 + 2] = col[i][2];
         }
+        float delta = NERF_DELTA;  // nerf.c:35
+        if (SPACING) {
+            const float* off = sp.offsets ? sp.offsets + (size_t)ray * S : nullptr;
+            delta = sample_spacing(min(s, S - 1), S, sp.near_plane, sp.far_plane, off);
+        }
+        const float a = 1.0f - expf_cr(-d * delta);
+        alpha[i] = s < S ? a : 0.0f;
         local *= (1.0f - alpha[i]);
     }
-    float T = SPACING ? wave_exclusive_product(local, lane) : sequential_transmittance<SPL>(alpha, lane);
+    float T = wave_exclusive_product(local, lane);
+    if (!SPACING) {
+        // does any sample's transmittance sit too close to the stop for the scan to decide it?
+        const float band = guard_band(S);
+        bool near = false;
+        float t = T;
+#pragma unroll
+        for (int i = 0; i < SPL; i++) {
+            near = near || fabsf(t - NERF_T_STOP) <= band;
+            t *= (1.0f - alpha[i]);
+        }
+        if (__builtin_amdgcn_ballot_w64(near) != 0ull) T = sequential_transmittance<SPL>(alpha, lane);  // wave-uniform
+    }
     float acc[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
@@ -199,29 +288,32 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
     if (ray >= R) return;
     const float e0 = err[ray * 3 + 0], e1 = err[ray * 3 + 1], e2 = err[ray * 3 + 2];
 
-    float alpha[SPL], col[SPL][3], dens[SPL], q[SPL], delta[SPL];
+    f32x4 y[SPL];  // as in the forward kernel: all loads first, clamped to the ray
+#pragma unroll
+    for (int i = 0; i < SPL; i++) {
+        const int s = min(lane * SPL + i, S - 1);
+        y[i] = fetch_sample<RAW>(raw, out_dim, dens_in, rgb_in, (size_t)ray * S + s);
+    }
+    float alpha[SPL], col[SPL][3], dens[SPL], q[SPL], delta[SPL], ex[SPL];
     float local = 1.0f;
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
         const int s = lane * SPL + i;
-        alpha[i] = 0.0f; dens[i] = 0.0f; q[i] = 0.0f; delta[i] = NERF_DELTA;
-        col[i][0] = col[i][1] = col[i][2] = 0.0f;
-        if (s < S) {
-            const size_t p = (size_t)ray * S + s;
-            load_sample<RAW>(raw, out_dim, dens_in, rgb_in, p, dens[i], col[i]);
-            if (SPACING) {
-                const float* off = sp.offsets ? sp.offsets + (size_t)ray * S : nullptr;
-                delta[i] = sample_spacing(s, S, sp.near_plane, sp.far_plane, off);
-            }
-            alpha[i] = 1.0f - expf_cr(-dens[i] * delta[i]);                    // nerf.c:79
-            q[i] = e0 * col[i][0] + e1 * col[i][1] + e2 * col[i][2];            // nerf.c:105-107
+        activate_sample<RAW>(y[i], dens[i], col[i]);
+        delta[i] = NERF_DELTA;
+        if (SPACING) {
+            const float* off = sp.offsets ? sp.offsets + (size_t)ray * S : nullptr;
+            delta[i] = sample_spacing(min(s, S - 1), S, sp.near_plane, sp.far_plane, off);
         }
+        ex[i] = expf_cr(-dens[i] * delta[i]);                                   // nerf.c:79 and nerf.c:101 take the same value
+        alpha[i] = s < S ? 1.0f - ex[i] : 0.0f;
+        q[i] = e0 * col[i][0] + e1 * col[i][1] + e2 * col[i][2];                // nerf.c:105-107
         local *= (1.0f - alpha[i]);
     }
     // transmittance in front of each sample, no early stop (nerf.c:82-86)
     float Tbefore[SPL];
     {
-        float T = SPACING ? wave_exclusive_product(local, lane) : sequential_transmittance<SPL>(alpha, lane);
+        float T = wave_exclusive_product(local, lane);
 #pragma unroll
         for (int i = 0; i < SPL; i++) {
             Tbefore[i] = T;
@@ -293,7 +385,7 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
         const float Rs = a * (aq_next[i] + Rn);
         if (s < S) {
             const float w = alpha[i] * Tbefore[i];                              // nerf.c:86
-            const float da = NERF_DELTA * expf_cr(-dens[i] * NERF_DELTA);      // nerf.c:101
+            const float da = NERF_DELTA * ex[i];                                // nerf.c:101
             const float gd = da * (Tbefore[i] * q[i] - Rs);
             f32x4 g;
             g[0] = dens[i] > 0.0f ? gd : 0.0f;                                  // nerf.c:123-124
@@ -312,7 +404,7 @@ __global__ __launch_bounds__(256) void activation_kernel(const float* __restrict
     if (i >= n) return;
     const float* o = y + (size_t)i * out_dim;
     dens[i] = fmaxf(0.0f, o[0]);
-    rgb[i * 3 + 0] = sigmoid_ref(o[1]);
+    rgb[i * 3 + 0] = sigmoid_ref(o[1]);  // the arithmetic of activate_sample<true>
     rgb[i * 3 + 1] = sigmoid_ref(o[2]);
     rgb[i * 3 + 2] = sigmoid_ref(o[3]);
 }

@@ -8,8 +8,6 @@ pytestmark = pytest.mark.gpu
 # pixel colours are sums of <= S products in [0,1]: fp32 reassociation stays below this
 PIX_ATOL = 2e-6
 GRAD_RTOL = 1e-4   # the tolerance the parity contract states for gradients
-GUARD = 1e-4       # rays whose transmittance passes within 1e-4 (relative) of the 0.01 stop are
-                   # excluded from the pixel check: expf differs by an ulp between host and device
 
 
 def random_raw(rng, R, S, dense_frac=0.3):
@@ -42,15 +40,12 @@ def test_launchers_match_oracle(gpu, oracle, R, S):
     d_pix, d_err, d_loss = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray.zeros((1,))
     lib.volume_rendering_and_loss_launch(d_dens.ptr, d_rgb.ptr, d_t.ptr, d_pix.ptr, d_err.ptr, d_loss.ptr, R, S)
     pix, err, loss = d_pix.numpy(), d_err.numpy(), float(d_loss.numpy()[0])
-    o_pix, o_err, o_loss, guard = oracle.composite_and_loss(dens, rgb, target_rep, R, S)
-    safe = guard > GUARD
-    assert safe.mean() > 0.8
-    np.testing.assert_allclose(pix[safe], o_pix[safe], rtol=0, atol=PIX_ATOL)
-    np.testing.assert_allclose(err[safe], o_err[safe], rtol=0, atol=PIX_ATOL)
-    # a flipped stop decision changes a pixel by at most the 1% transmittance that is left
-    assert np.abs(pix - o_pix).max() <= 0.0101
-    if safe.all():
-        assert loss == pytest.approx(o_loss, rel=1e-5, abs=1e-6)
+    # every ray, however close its transmittance comes to the 0.01 stop: the device takes the
+    # sequential loop's decision (alpha comes from a correctly rounded expf on both sides)
+    o_pix, o_err, o_loss, _ = oracle.composite_and_loss(dens, rgb, target_rep, R, S)
+    np.testing.assert_allclose(pix, o_pix, rtol=0, atol=PIX_ATOL)
+    np.testing.assert_allclose(err, o_err, rtol=0, atol=PIX_ATOL)
+    assert loss == pytest.approx(o_loss, rel=1e-5, abs=1e-6)
     # loss accumulates (train.c:202 zeroes it first): a second launch doubles it
     lib.volume_rendering_and_loss_launch(d_dens.ptr, d_rgb.ptr, d_t.ptr, d_pix.ptr, d_err.ptr, d_loss.ptr, R, S)
     assert float(d_loss.numpy()[0]) == pytest.approx(2 * loss, rel=1e-6)
