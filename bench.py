@@ -297,6 +297,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
     lib.nerf_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    # N > 1 on GPUs: the gradient all-reduce is the library's own RCCL call (nerf_dp_*); the torch
+    # process group only carries the communicator id and the barriers around the timed region
+    group = dp.RcclGroup() if world > 1 and not args.rehearse_on_one_gpu else None
 
     if args.workload == "render":
         return render_workload(args, lib, torch)
@@ -317,7 +320,7 @@ def main():
     grads = dp.arena_tensor(n_params + 4, device)
     tr = Trainer(cfg, param_arena=params.data_ptr(), grad_arena=grads.data_ptr())
     tr.init_weights(seed=1, use_rand=False)  # deterministic LCG: identical on every rank
-    dp.broadcast_params(params)
+    dp.broadcast_params(params, group=group)
     trace("weights broadcast")
 
     total_steps = args.warmup + args.steps
@@ -340,7 +343,7 @@ def main():
             if lr_state["t"] % 10000 == 0:  # train.c:171-173
                 lr_state["lr"] = float(np.float32(lr_state["lr"]) * np.float32(0.99))
             lr_state["t"] += 1
-            dp.DataParallelStep(fwd_bwd_for(step), tr.update, grads, R * S).step(lr_state["lr"])
+            dp.DataParallelStep(fwd_bwd_for(step), tr.update, grads, R * S, group=group).step(lr_state["lr"])
 
     def fence():
         torch.cuda.synchronize()
@@ -458,6 +461,8 @@ def main():
 
     if world > 1:
         dist.barrier()
+        if group is not None:
+            group.destroy()
         dist.destroy_process_group()
 
 

@@ -283,6 +283,37 @@ int nerf_trainer_encoding_pitch(const NerfTrainer* tr);
  * (after backward: its gradient), 4 layer-3 pre-activation, 5 layer-3 activation (after backward: error) */
 const unsigned short* nerf_trainer_buffer_bf16(NerfTrainer* tr, int which);
 
+/* ---- data parallelism over rays: RCCL from C.  No counterpart in the reference, which is single-GPU
+ * (train.c:48).  One process per GPU; each rank runs nerf_trainer_forward_backward on its own rays, one
+ * all-reduce(sum) over the gradient arena ([param_count gradients | squared error + 3 spare floats])
+ * follows, and every rank applies the same AdamW step with the GLOBAL point count as divisor, so the
+ * weights stay equal on all ranks after one broadcast at the start.  RCCL (librccl.so.1) is loaded
+ * when the first of these functions is called; collectives run on the library's stream. -------------- */
+#define NERF_DP_ID_BYTES 128
+typedef struct NerfDp NerfDp;
+/* rank 0 creates the communicator's id and hands its 128 bytes to the other ranks by any means */
+int nerf_dp_unique_id(unsigned char* id128);
+/* joins the communicator on the CURRENT device (nerf_set_device first); returns once all `world` ranks
+ * have joined.  NULL on failure. */
+NerfDp* nerf_dp_init(int rank, int world, const unsigned char* id128);
+/* the same with the id handed over through a file all ranks can reach: rank 0 writes it, the others
+ * wait up to timeout_seconds (<= 0: 120) for it to appear; rank 0 removes it afterwards */
+NerfDp* nerf_dp_init_from_file(int rank, int world, const char* path, int timeout_seconds);
+void nerf_dp_destroy(NerfDp* dp);
+int nerf_dp_rank(const NerfDp* dp);
+int nerf_dp_world(const NerfDp* dp);
+/* in place on a device buffer of `count` floats */
+int nerf_dp_allreduce_sum(NerfDp* dp, float* d_buf, size_t count);
+int nerf_dp_broadcast(NerfDp* dp, float* d_buf, size_t count, int root);
+/* the trainer's gradient arena (gradients + squared error) summed over ranks; its weights from `root` */
+int nerf_dp_allreduce_grads(NerfDp* dp, NerfTrainer* tr);
+int nerf_dp_broadcast_params(NerfDp* dp, NerfTrainer* tr, int root);
+/* nerf_trainer_step for rank-local rays: learning-rate decay check, forward/backward, all-reduce,
+ * AdamW on gradient / (rays * samples * world).  nerf_trainer_last_loss then reports the GLOBAL squared
+ * error over this rank's ray count: divide by the world size for the loss per ray. */
+int nerf_trainer_step_dp(NerfTrainer* tr, NerfDp* dp, const NerfDeviceDataset* dataset, const int* d_idx,
+                         const float* d_offsets);
+
 /* ---- forward-only render (nerf.c:259-316 for a whole view, chunked over rays) ------------------ */
 /* host_rgb8 [render_h*render_w*3] and/or host_pixel [render_h*render_w*3] (either may be NULL) */
 int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,

@@ -197,6 +197,18 @@ _SIGS = {
     "nerf_trainer_steps_done": (C.c_int, [VP]),
     "nerf_trainer_buffer": (VP, [VP, C.c_int]),
     "nerf_trainer_encoding_pitch": (C.c_int, [VP]),
+    # data parallelism (RCCL from C)
+    "nerf_dp_unique_id": (C.c_int, [VP]),
+    "nerf_dp_init": (VP, [C.c_int, C.c_int, VP]),
+    "nerf_dp_init_from_file": (VP, [C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "nerf_dp_destroy": (None, [VP]),
+    "nerf_dp_rank": (C.c_int, [VP]),
+    "nerf_dp_world": (C.c_int, [VP]),
+    "nerf_dp_allreduce_sum": (C.c_int, [VP, VP, C.c_size_t]),
+    "nerf_dp_broadcast": (C.c_int, [VP, VP, C.c_size_t, C.c_int]),
+    "nerf_dp_allreduce_grads": (C.c_int, [VP, VP]),
+    "nerf_dp_broadcast_params": (C.c_int, [VP, VP, C.c_int]),
+    "nerf_trainer_step_dp": (C.c_int, [VP, VP, VP, VP, VP]),
     "nerf_render_release": (None, []),
     "nerf_render_view": (C.c_int, [C.POINTER(MLP), C.POINTER(MLP), C.POINTER(Camera), C.c_int, C.c_int, C.c_int,
                                    C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, VP, VP]),

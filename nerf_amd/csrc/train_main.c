@@ -18,17 +18,27 @@
  *
  *   ./train [--data DIR] [--images N] [--rays R] [--samples S] [--batches B] [--path classic|fused]
  *           [--render-every K] [--log-every K] [--seed X] [--save PREFIX] [--math exact|split-bf16]
- *           [--fuse-pair 0|1] [--pin 0|1] [model1.bin model2.bin]
+ *           [--fuse-pair 0|1] [--pin 0|1] [--ranks N] [model1.bin model2.bin]
  *
  * --math split-bf16 and --fuse-pair 1 are this library's opt-in speed-ups (include/nerf_amd.h:
  * NERF_PRECISION_SPLIT_BF16, fuse_linear_pair); the defaults run the reference's arithmetic and layer
  * arrangement.  --fuse-pair needs the device-side step (--path fused, the default).
+ *
+ * --ranks N (device-side step only; the reference is single-GPU, train.c:48): data parallelism over
+ * rays.  The driver forks into N processes before anything touches the GPU, rank r takes device r,
+ * every rank draws and trains its own --rays rays per step, the weight gradients and the squared error
+ * are summed with one RCCL all-reduce (nerf_dp_*), and every rank applies the same AdamW step with the
+ * global point count as divisor.  Rank 0 logs (loss over the global batch), renders and saves.
+ * --ranks 1 runs the same code path on one GPU.
  */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "nerf_amd.h"
 #include "nerf_kernels.h"
@@ -38,6 +48,7 @@ typedef struct {
     const char* data_dir;
     int max_images, rays, samples, batches, fused, render_every, log_every;
     int split_math, fuse_pair, pin;
+    int ranks; /* 0: no communicator at all (the default); N >= 1: N processes, one per GPU */
     long seed; /* < 0: srand(time(NULL)) and rand() everywhere, like train.c:13.  >= 0: repeatable run (see main) */
     const char* save_prefix;
     const char* resume[2];
@@ -56,6 +67,7 @@ static int parse_options(int argc, char** argv, Options* o) {
     o->split_math = 0;
     o->fuse_pair = 0;
     o->pin = 1;
+    o->ranks = 0;
     o->save_prefix = NULL;
     o->resume[0] = o->resume[1] = NULL;
     int positional = 0;
@@ -79,6 +91,7 @@ static int parse_options(int argc, char** argv, Options* o) {
                 else if (strcmp(v, "exact") != 0) return -1;
             } else if (!strcmp(a, "--fuse-pair")) o->fuse_pair = atoi(v) != 0;
             else if (!strcmp(a, "--pin")) o->pin = atoi(v) != 0;
+            else if (!strcmp(a, "--ranks")) o->ranks = atoi(v);
             else return -1;
             i++;
         } else if (positional < 2) {
@@ -88,6 +101,7 @@ static int parse_options(int argc, char** argv, Options* o) {
         }
     }
     if (positional == 1) return -1; /* train.c:127-131: none or both */
+    if (o->ranks < 0 || o->ranks > 64) return -1;
     return 0;
 }
 
@@ -175,7 +189,7 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Usage: %s [options] [model1.bin model2.bin]\n"
                         "  no model files: start new training; two: continue from them\n"
                         "  --data DIR --images N --rays R --samples S --batches B --path classic|fused\n"
-                        "  --render-every K --log-every K --seed X --save PREFIX\n", argv[0]);
+                        "  --render-every K --log-every K --seed X --save PREFIX --ranks N\n", argv[0]);
         return -1;
     }
 
@@ -191,7 +205,47 @@ int main(int argc, char** argv) {
         return -1;
     }
 
-    CHECK_HIP(nerf_set_device(0));
+    /* data parallelism: one process per GPU, forked while the process is still GPU-free (the dataset
+     * above is host memory and is shared copy-on-write) */
+    int rank = 0;
+    const int world = o.ranks > 0 ? o.ranks : 1;
+    pid_t kids[64];
+    char id_path[128] = "";
+    if (o.ranks > 0 && !o.fused) {
+        fprintf(stderr, "--ranks needs --path fused\n");
+        return -1;
+    }
+    if (o.ranks > 0) snprintf(id_path, sizeof(id_path), "/tmp/nerf_dp_%ld.id", (long)getpid());
+    fflush(NULL);
+    for (int r = 1; r < world; r++) {
+        const pid_t p = fork();
+        if (p < 0) {
+            perror("fork");
+            return -1;
+        }
+        if (p == 0) {
+            rank = r;
+            break;
+        }
+        kids[r] = p;
+    }
+    if (world > nerf_device_count()) {
+        if (rank == 0) fprintf(stderr, "--ranks %d needs %d GPUs, %d visible\n", world, world, nerf_device_count());
+        return -1;
+    }
+    CHECK_HIP(nerf_set_device(rank));
+    NerfDp* dp = NULL;
+    if (o.ranks > 0) {
+        dp = nerf_dp_init_from_file(rank, world, id_path, 120);
+        if (!dp) {
+            fprintf(stderr, "rank %d: failed to join the communicator\n", rank);
+            return -1;
+        }
+    }
+    if (rank != 0) { /* rank 0 speaks for the run */
+        if (!freopen("/dev/null", "w", stdout)) return -1;
+        o.render_every = 0;
+    }
     char name[256];
     int cus = 0, khz = 0;
     size_t mem = 0;
@@ -200,7 +254,7 @@ int main(int argc, char** argv) {
     /* train.c:13.  The HIP runtime draws from rand() itself (first allocations, first launches), so
      * one srand() cannot make a run repeatable.  With --seed the weights come from the library's
      * own generator and rand() is re-seeded right before every batch's three-draws-per-ray. */
-    srand(o.seed < 0 ? (unsigned)time(NULL) : (unsigned)o.seed);
+    srand((o.seed < 0 ? (unsigned)time(NULL) : (unsigned)o.seed) + 104729u * (unsigned)rank);
 
     /* MLPs: fresh, or resumed with the reference's dimension check */
     MLP *mlp1 = NULL, *mlp2 = NULL;
@@ -291,6 +345,9 @@ int main(int argc, char** argv) {
         CHECK_HIP(nerf_mlp_set_matrix_math(mlp2, o.split_math));
     }
 
+    /* every rank starts from rank 0's weights, moments aside (they are zero, or were loaded alike) */
+    if (dp) CHECK_HIP(nerf_dp_broadcast_params(dp, trainer, 0));
+
     ClassicBuffers cb;
     memset(&cb, 0, sizeof(cb));
     int* idx = NULL;
@@ -316,26 +373,27 @@ int main(int argc, char** argv) {
     const double t0 = seconds_now();
     for (int batch = first; batch < first + o.batches; batch++) {
         if (batch % NERF_LR_DECAY_EVERY == 0) lr *= NERF_LR_DECAY;
-        if (o.seed >= 0) srand((unsigned)(o.seed + 7919L * (batch + 1)));
+        if (o.seed >= 0) srand((unsigned)(o.seed + 7919L * (batch + 1) + 104729L * rank));
         if (o.fused) {
             nerf_draw_ray_indices(ds, o.rays, idx);
             CHECK_HIP(nerf_memcpy_h2d(d_idx, idx, (size_t)o.rays * 3 * sizeof(int)));
             CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx, NULL));
-            CHECK_HIP(nerf_trainer_update(trainer, lr, points));
+            if (dp) CHECK_HIP(nerf_dp_allreduce_grads(dp, trainer)); /* gradients and squared error of all ranks */
+            CHECK_HIP(nerf_trainer_update(trainer, lr, points * world));
         } else {
             classic_step(&o, ds, mlp1, mlp2, &cb, pe_dim, lr);
         }
         if (o.log_every > 0 && (batch + 1) % o.log_every == 0) {
             float loss;
             if (o.fused) {
-                loss = nerf_trainer_last_loss(trainer);
+                loss = nerf_trainer_last_loss(trainer) / (float)world; /* the sum is global, the divisor per rank */
             } else {
                 CHECK_HIP(nerf_memcpy_d2h(&loss, cb.d_loss, sizeof(float)));
                 loss /= (float)o.rays;
             }
             const double el = seconds_now() - t0;
             printf("Batch [%d/%d], Loss: %.6f, LR: %.6f  (%.0f rays/s)\n", batch + 1, first + o.batches, loss, lr,
-                   (double)(batch + 1 - first) * o.rays / el);
+                   (double)(batch + 1 - first) * o.rays * world / el);
             if (o.render_every > 0 && (batch + 1) % o.render_every == 0)
                 render_test_image(mlp1, mlp2, ds, batch + 1, NULL, o.samples, NERF_DEFAULT_NEAR, NERF_DEFAULT_FAR,
                                   NERF_DEFAULT_POS_ENC_L, NERF_DEFAULT_DIR_ENC_L, pe_dim, 128, 128);
@@ -343,6 +401,8 @@ int main(int argc, char** argv) {
     }
     CHECK_HIP(nerf_stream_synchronize());
 
+    int status = 0;
+    if (rank != 0) goto cleanup; /* one copy of the model is enough: all ranks hold the same weights */
     char file1[300], file2[300];
     if (o.save_prefix) {
         snprintf(file1, sizeof(file1), "%s_nerf_model1.bin", o.save_prefix);
@@ -356,6 +416,8 @@ int main(int argc, char** argv) {
     save_mlp(mlp2, file2);
     printf("\nTraining completed! Models saved to: %s and %s\n", file1, file2);
 
+cleanup:
+    if (dp) nerf_dp_destroy(dp);
     if (o.fused) {
         free(idx);
         nerf_device_free(d_idx);
@@ -367,5 +429,13 @@ int main(int argc, char** argv) {
         free_mlp(mlp2);
     }
     free_dataset(ds);
-    return 0;
+    if (rank == 0)
+        for (int r = 1; r < world; r++) {
+            int st = 0;
+            if (waitpid(kids[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                fprintf(stderr, "rank %d did not finish cleanly\n", r);
+                status = -1;
+            }
+        }
+    return status;
 }

@@ -493,6 +493,30 @@ int nerf_trainer_step(NerfTrainer* tr, const NerfDeviceDataset* dataset, const i
     return nerf_trainer_update(tr, tr->learning_rate, tr->cfg.rays_per_batch * tr->cfg.num_samples);
 }
 
+// ---- the step over several GPUs (declared in include/nerf_amd.h; collectives in dp.hip) ------------
+int nerf_dp_allreduce_grads(NerfDp* dp, NerfTrainer* tr) {
+    if (!dp || !tr) return NERF_ERR_ARG;
+    return nerf_dp_allreduce_sum(dp, tr->d_grads, tr->n_params + 4);  // gradient sums and the squared error in one go
+}
+
+int nerf_dp_broadcast_params(NerfDp* dp, NerfTrainer* tr, int root) {
+    if (!dp || !tr) return NERF_ERR_ARG;
+    return nerf_dp_broadcast(dp, tr->d_params, tr->n_params, root);
+}
+
+int nerf_trainer_step_dp(NerfTrainer* tr, NerfDp* dp, const NerfDeviceDataset* dataset, const int* d_idx,
+                         const float* d_offsets) {
+    if (!tr || !dp) return NERF_ERR_ARG;
+    if (tr->mlp1->t % NERF_LR_DECAY_EVERY == 0) tr->learning_rate *= NERF_LR_DECAY;  // train.c:171-173, on every rank alike
+    int rc = nerf_trainer_forward_backward(tr, dataset, d_idx, d_offsets);
+    if (rc != NERF_OK) return rc;
+    rc = nerf_dp_allreduce_grads(dp, tr);
+    if (rc != NERF_OK) return rc;
+    const long long points = (long long)tr->cfg.rays_per_batch * tr->cfg.num_samples * nerf_dp_world(dp);
+    if (points > 0x7fffffffLL) return NERF_ERR_ARG;
+    return nerf_trainer_update(tr, tr->learning_rate, (int)points);
+}
+
 float nerf_trainer_last_loss(NerfTrainer* tr) {
     float sse = 0.0f;
     if (nerf_memcpy_d2h(&sse, tr->d_grads + tr->n_params, sizeof(float)) != NERF_OK) return NAN;

@@ -7,11 +7,55 @@ all-reduce(sum) over the flat [gradients | sse] buffer follows (RCCL over xGMI w
 on a GPU, gloo on the CPU), and every rank applies the identical AdamW update with the GLOBAL
 point count as divisor -- so weights stay equal on all ranks without ever being broadcast again.
 
+On GPUs the collectives are the library's own RCCL entry points (nerf_dp_* of include/nerf_amd.h,
+one communicator per process, enqueued on the library's stream): RcclGroup below only carries the
+communicator's id from rank 0 to the others over the process group the launcher set up.  The
+torch.distributed calls remain for host tensors (gloo), which is what the CPU tests and the
+several-ranks-on-one-GPU rehearsal use.
+
 The compute is injected (callables), so the same code drives the HIP trainer on GPUs and the CPU
 checker in the world_size-2 gloo tests.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+
+class RcclGroup:
+    """A communicator of the HIP library (nerf_dp_init) spanning the ranks of a torch process group.
+
+    The process group (any backend) is used once, to hand rank 0's 128-byte id to the other ranks;
+    every collective afterwards is the library's own RCCL call on the library's stream."""
+
+    def __init__(self, group=None):
+        from ._lib import lib
+        self.lib = lib
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        uid = (ctypes.c_ubyte * 128)()
+        if self.rank == 0 and lib.nerf_dp_unique_id(uid) != 0:
+            raise RuntimeError("nerf_dp_unique_id failed (is librccl.so.1 installed?)")
+        if self.world_size > 1:
+            box = [bytes(uid)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        self.handle = lib.nerf_dp_init(self.rank, self.world_size, uid)
+        if not self.handle:
+            raise RuntimeError("nerf_dp_init failed")
+
+    def all_reduce_sum(self, ptr, count):
+        if self.lib.nerf_dp_allreduce_sum(self.handle, ptr, count) != 0:
+            raise RuntimeError("nerf_dp_allreduce_sum failed")
+
+    def broadcast(self, ptr, count, root=0):
+        if self.lib.nerf_dp_broadcast(self.handle, ptr, count, root) != 0:
+            raise RuntimeError("nerf_dp_broadcast failed")
+
+    def destroy(self):
+        if self.handle:
+            self.lib.nerf_dp_destroy(self.handle)
+            self.handle = None
 
 
 def _host_staged(tensor, group):
@@ -20,9 +64,12 @@ def _host_staged(tensor, group):
 
 
 def all_reduce_sum(flat, group=None):
-    """in-place sum over ranks: RCCL on device tensors (backend nccl), gloo on host tensors; a device
-    tensor under gloo (rehearsing several ranks on one GPU) goes through a host copy"""
-    if _host_staged(flat, group):
+    """in-place sum over ranks: the library's RCCL communicator when `group` is an RcclGroup (device
+    tensors), else torch.distributed -- gloo on host tensors; a device tensor under gloo (rehearsing
+    several ranks on one GPU) goes through a host copy"""
+    if isinstance(group, RcclGroup):
+        group.all_reduce_sum(flat.data_ptr(), flat.numel())
+    elif _host_staged(flat, group):
         tmp = flat.cpu()
         dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
         flat.copy_(tmp)
@@ -51,7 +98,10 @@ class DataParallelStep:
         self.update = update
         self.flat = flat
         self.group = group
-        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        if isinstance(group, RcclGroup):
+            self.world_size = group.world_size
+        else:
+            self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.global_points = local_points * self.world_size
 
     def step(self, lr):
@@ -63,7 +113,10 @@ class DataParallelStep:
 
 def broadcast_params(params, src=0, group=None):
     """make every rank start from rank `src`'s weights (a 1-D tensor, in place)"""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if isinstance(group, RcclGroup):
+        if group.world_size > 1:
+            group.broadcast(params.data_ptr(), params.numel(), src)
+    elif dist.is_initialized() and dist.get_world_size(group) > 1:
         if _host_staged(params, group):
             tmp = params.cpu()
             dist.broadcast(tmp, src=src, group=group)
