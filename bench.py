@@ -45,6 +45,25 @@ SPLIT_KERNEL = {
 SPLIT_WORDS_KERNEL = {k: v.replace(", false>", ", true>") for k, v in SPLIT_KERNEL.items()}
 
 
+def rocprof_avg_ms(kernel, mode=""):
+    """Average launch duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of
+    this same command (profiles/rNN_<mode>bench_kernel_stats.csv), latest round first; (ms, file) or
+    (None, None).  Beside the HIP-event figure in `roofline` so the two can be compared."""
+    import csv
+    import glob
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_bench_kernel_stats.csv"))
+                   if re.fullmatch(r"r\d+_" + mode + r"bench_kernel_stats\.csv", os.path.basename(f)))
+    for path in reversed(files):
+        try:
+            for row in csv.DictReader(open(path)):
+                if kernel in row["Name"]:
+                    return float(row["AverageNs"]) * 1e-6, os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def pmc_traffic(kernel, mode=""):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
     command (profiles/rNN_<mode>pmc_summary.json, written by tools/pmc_summary.py: FETCH_SIZE doubled
@@ -56,15 +75,15 @@ def pmc_traffic(kernel, mode=""):
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))
                    if re.fullmatch(r"r\d+_" + mode + "pmc_summary\.json", os.path.basename(f)))
     if not files:
-        return None, None
+        return None, None, None
     for path in reversed(files):  # latest round first; a summary only holds the kernels its command ran
         try:
             rec = json.load(open(path)).get(kernel)
         except (OSError, ValueError):
             continue
         if rec and "hbm_read_bytes" in rec and "hbm_write_bytes" in rec:
-            return rec["hbm_read_bytes"] + rec["hbm_write_bytes"], rec.get("mfma_util")
-    return None, None
+            return rec["hbm_read_bytes"] + rec["hbm_write_bytes"], rec.get("mfma_util"), os.path.relpath(path, ROOT)
+    return None, None, None
 
 
 def cpu_baseline(seconds=12.0, rays=64, samples=128):
@@ -160,7 +179,7 @@ def render_workload(args, lib, torch):
     if split:  # three bf16 products are executed per algorithmic product: executed bf16 FLOP/s against the bf16 peak
         achieved, peak = achieved * 3.0, PEAK_BF16_MFMA_TFLOPS
         kernel = SPLIT_KERNEL["gemm_fwd"] + " (forward products, 3 x v_mfma_f32_32x32x16_bf16 each; achieved = executed bf16 FLOP/s)"
-    print(json.dumps({
+    return ({
         "metric": "rendered rays/s @128 samples/ray (forward only)", "value": W * H * steps / el, "unit": "rays/s",
         "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": el / steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
@@ -174,7 +193,7 @@ def render_workload(args, lib, torch):
                      "frac": achieved / peak, "traffic": None,
                      "gemm_share_of_step": ms / (el * 1e3)},
         "mean_byte": float(np.mean(rgb8)),
-    }), flush=True)
+    })
 
 
 def bf16_workload(args, lib, torch):
@@ -222,7 +241,7 @@ def bf16_workload(args, lib, torch):
     all_work = sum(v[2] for v in gemm.values())
     dom = max(gemm, key=lambda k: gemm[k][0])
     achieved = gemm[dom][2] / (gemm[dom][0] * 1e-3) / 1e12
-    print(json.dumps({
+    out = ({
         "metric": "trained rays/s @256 samples/ray, bf16 operands", "value": rays_total * steps / el, "unit": "rays/s",
         "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": el / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 operands, f32 accumulate",
@@ -235,7 +254,10 @@ def bf16_workload(args, lib, torch):
                      "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12, "gemm_share_of_step": all_ms / (el * 1e3),
                      "kernels": {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in prof.items()
                                  if v[1] > 0}},
-    }), flush=True)
+    })
+    tr.destroy()
+    dds.release()
+    return out
 
 
 def main():
@@ -260,6 +282,9 @@ def main():
                          "between them) into one product per point, gradients of both derived from it; same "
                          "parameters and results to fp32 rounding, 45 %% fewer FLOPs; reported separately")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N = 1 train workload: do not append the forward-only render and the bf16 configuration "
+                         "(each a short run of its own after the headline has been timed) as `secondary`")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on device 0 with the gloo backend: exercises the multi-rank code path "
                          "on a one-GPU box (RCCL refuses two ranks on one device); the number is meaningless")
@@ -302,9 +327,11 @@ def main():
     group = dp.RcclGroup() if world > 1 and not args.rehearse_on_one_gpu else None
 
     if args.workload == "render":
-        return render_workload(args, lib, torch)
+        print(json.dumps(render_workload(args, lib, torch)), flush=True)
+        return
     if args.workload == "bf16":
-        return bf16_workload(args, lib, torch)
+        print(json.dumps(bf16_workload(args, lib, torch)), flush=True)
+        return
 
     R, S = args.rays, args.samples
     host = synthetic_dataset(num_images=100, width=800, height=800, seed=1234)  # same scene on every rank
@@ -357,15 +384,25 @@ def main():
         trace(f"warmup step {s} enqueued")
     fence()
     trace("warmup done")
-    lib.nerf_prof_reset()
-    lib.nerf_prof_enable(1)
+    # the headline: K steps with nothing but the step's own launches on the stream
+    lib.nerf_prof_enable(0)
     t0 = time.perf_counter()
     for s in range(args.warmup, total_steps):
         run_step(s)
     fence()
     elapsed = time.perf_counter() - t0
-    lib.nerf_prof_enable(0)
     trace("timed steps done")
+    # the per-kernel figures: the same K batches once more, every launch between two events on the
+    # library's stream (26 event pairs per step: kept out of the headline's clock)
+    lib.nerf_prof_reset()
+    lib.nerf_prof_enable(1)
+    t1 = time.perf_counter()
+    for s in range(args.warmup, total_steps):
+        run_step(s)
+    fence()
+    elapsed_events = time.perf_counter() - t1
+    lib.nerf_prof_enable(0)
+    trace("event pass done")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -391,8 +428,9 @@ def main():
         all_ms = sum(v[0] for v in gemm.values())
         all_work = sum(v[2] for v in gemm.values())
         names = (SPLIT_WORDS_KERNEL if fused else SPLIT_KERNEL) if split else GEMM_KERNEL
-        traffic, mfma_util = pmc_traffic(names[dom],
-                                          ("fused_" if fused else "") + ("split_" if split else ""))
+        mode = ("fused_" if fused else "") + ("split_" if split else "")
+        traffic, mfma_util, traffic_file = pmc_traffic(names[dom], mode)
+        prof_ms, prof_file = rocprof_avg_ms(names[dom], mode)
         ksteps = 32 if dom == "gemm_wgrad" else 16
         kernel_label = f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x{ksteps} tiles, LDS-DMA staged)"
         peak = PEAK_F32_MFMA_TFLOPS
@@ -414,16 +452,24 @@ def main():
             "unit": "TFLOP/s",
             "frac": achieved / peak,
             "avg_launch_ms": dms / dlaunch,
+            "avg_launch_ms_source": "HIP events on the library's stream, in this run: a second pass over the K timed "
+                                    "batches (the headline pass carries no events)",
+            "avg_launch_ms_rocprof": prof_ms,
+            "avg_launch_ms_rocprof_source": prof_file and f"{prof_file} (rocprofv3 --kernel-trace --stats of an earlier "
+                                                          "run of this command: another box, another clock)",
+            "frac_rocprof": None if not prof_ms else (dwork / dlaunch) / (prof_ms * 1e-3) / 1e12 * (3.0 if split else 1.0) / peak,
             "flop_per_launch": dwork / dlaunch,
             "traffic": traffic,
-            "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, "
-                            "profiles/*_pmc_summary.json)",
+            "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+            "traffic_source": traffic_file and f"{traffic_file}: counters of an earlier run of this command, not of "
+                                               "this run (they cannot be read from inside the timed process)",
             "mfma_busy_frac_pmc": mfma_util,
+            "ms_per_step_with_events": elapsed_events / args.steps * 1e3,
             "step_flop_frac_of_peak": None if split else
             (flop_per_point * R * S) / (elapsed / args.steps) / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "executed_flop_per_point": flop_per_point,
             "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12,
-            "gemm_share_of_step": all_ms / (elapsed * 1e3),
+            "gemm_share_of_step": all_ms / (elapsed_events * 1e3),
             "kernels": kernels,
         }
         info = nerf_amd.api.device_info()
@@ -442,7 +488,9 @@ def main():
             "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (REHEARSAL: all ranks on one GPU, gloo)",
             "config": {
                 "workload": "full training step (encode + fwd + composite + bwd + AdamW), "
-                            f"{R} rays x {S} samples per GPU, MLP 150-512-512-512-4, "
+                            f"{R} rays x {S} samples per GPU, MLP 150-512-512-512-4, ray indices of every step drawn "
+                            "with rand() beforehand and resident in HBM (the reference's per-step draws and their "
+                            "48 KB upload are outside the clock), "
                             + ("fp32 with split-bf16 matrix products" if split else "fp32")
                             + (", linear pair fused (opt-in, not the benchmark of record)" if fused else ""),
                 "rays_per_gpu": R,
@@ -457,6 +505,18 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seconds=args.cpu_seconds)
+        if world == 1 and not args.no_secondary and not split and not fused and (R, S) == (4096, 128):
+            # the two other single-GPU configurations the baseline names, each a short run of its own
+            # after the headline (their numbers never enter `value`)
+            tr.destroy()
+            dds.release()
+            del params, grads, d_idx
+            sec_args = argparse.Namespace(**vars(args))
+            sec_args.rays, sec_args.samples, sec_args.steps, sec_args.warmup = 4096, 128, 3, 1
+            out["secondary"] = {"render_800x800_fp32": render_workload(sec_args, lib, torch)}
+            lib.nerf_render_release()
+            sec_args.steps = 2
+            out["secondary"]["bf16_1M_rays_x_256_width_1024"] = bf16_workload(sec_args, lib, torch)
         print(json.dumps(out), flush=True)
 
     if world > 1:
