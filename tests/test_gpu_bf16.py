@@ -304,3 +304,90 @@ def test_fp32_micro_batches_add_up(gpu, oracle):
     tr.forward_backward(dds, a); tr.forward_backward_add(dds, b); g, s = tr.get_grads()
     assert np.abs(g - (g1.astype(np.float64) + g2)).max() <= 2e-6 * np.abs(g).max()
     assert s == pytest.approx(s1 + s2, rel=1e-6)
+
+
+def test_bf16_step_at_the_stated_widths(gpu, oracle_fast):
+    """The reduced-precision configuration at the widths it is quoted on -- MLP 150-1024-512-1024-4, 256
+    samples per ray -- against the fp32 CPU oracle on identical weights and rays, small ray count (the
+    oracle's step at this width takes seconds): pixels within 2e-2 absolute, every weight-gradient
+    matrix within 6e-2 of its largest entry.  Sixteen rays x 256 samples are 4096 points: the products
+    run their 128x128 tiles; the 256x256 ones are exercised by the micro-batch test below."""
+    from oracle.pyoracle import ACC_F64
+    from nerf_amd.api import DeviceArray, Trainer
+    oracle = oracle_fast
+    p = Bf16Pair(gpu, oracle, R=16, S=256, Lp=16, Ld=8, hidden=1024, inter=512, gain=60.0)
+    R, S = p.R, p.S
+    idx = p.indices(12)
+    p.tr.forward_backward(p.dds, DeviceArray.from_numpy(idx))
+    m1 = oracle.init_mlp(p.pe, p.H, p.M, R * S, acc_mode=ACC_F64)
+    m2 = oracle.init_mlp(p.M, p.H, 4, R * S, acc_mode=ACC_F64)
+    a1, a2 = oracle.mlp_arrays(m1), oracle.mlp_arrays(m2)
+    a1["W1"][:], a1["W2"][:], a2["W1"][:], a2["W2"][:] = p.parts
+    buf = oracle.alloc_step(R, S, p.Lp, p.Ld)
+    X, col = oracle.batch_from_indices(p.ocams, p.images, idx, S, 2.0, 6.0)
+    o_sse = oracle.forward_backward(m1, m2, buf, X, col, scan_gradient=True)
+    st = oracle.step_arrays(buf)
+    assert np.array_equal(p.tr.buffer(Trainer.BUF_TARGET), col[::S])
+    assert np.abs(p.tr.buffer(Trainer.BUF_PIXEL) - st["pixel"]).max() <= 2e-2
+    grads, sse = p.tr.get_grads()
+    assert sse == pytest.approx(o_sse, rel=5e-2)
+    og = np.concatenate([a1["W1_grad"].ravel(), a1["W2_grad"].ravel(), a2["W1_grad"].ravel(), a2["W2_grad"].ravel()])
+    for off, shape in p.tr.param_slices():
+        n = shape[0] * shape[1]
+        assert np.abs(grads[off:off + n] - og[off:off + n]).max() <= 6e-2 * np.abs(og[off:off + n]).max(), shape
+    oracle.free_step(buf)
+    oracle.free_mlp(m1)
+    oracle.free_mlp(m2)
+    p.tr.destroy()
+
+
+def test_bf16_full_micro_batch_properties(gpu, oracle_fast):
+    """One micro-batch of the quoted configuration at full size -- 8192 rays x 256 samples = 2 097 152
+    points through 150-1024-512-1024-4, the shape the 256x256-tile kernels run at -- where the oracle's
+    step is out of reach: the step is reproducible bit for bit (no atomics), two half batches (4096
+    rays each, accumulated with forward_backward_add) give the full batch's sums up to the association of
+    the fp32 additions, pixels do not depend on the batch a ray is in, and the oracle's fp32 forward
+    pass on 12 scattered rays agrees to the stated 2e-2."""
+    from oracle.pyoracle import ACC_F64
+    from nerf_amd.api import DeviceArray, Trainer
+    oracle = oracle_fast
+    R, S = 8192, 256
+    full = Bf16Pair(gpu, oracle, R=R, S=S, Lp=16, Ld=8, hidden=1024, inter=512, gain=60.0)
+    idx = full.indices(99)
+    d_idx = DeviceArray.from_numpy(idx)
+    full.tr.forward_backward(full.dds, d_idx)
+    g_full, sse_full = full.tr.get_grads()
+    pix = full.tr.buffer(Trainer.BUF_PIXEL)
+    assert np.isfinite(g_full).all() and np.isfinite(pix).all() and sse_full > 0
+    full.tr.forward_backward(full.dds, d_idx)
+    g_again, sse_again = full.tr.get_grads()
+    assert sse_again == sse_full and np.array_equal(g_again, g_full)
+    params = full.tr.get_params()
+    full.tr.destroy()
+
+    half = Bf16Pair(gpu, oracle, R=R // 2, S=S, Lp=16, Ld=8, hidden=1024, inter=512, gain=60.0)
+    half.tr.set_params(params)
+    half.tr.forward_backward(half.dds, DeviceArray.from_numpy(np.ascontiguousarray(idx[:R // 2])))
+    assert np.array_equal(half.tr.buffer(Trainer.BUF_PIXEL), pix[:R // 2])
+    half.tr.forward_backward_add(half.dds, DeviceArray.from_numpy(np.ascontiguousarray(idx[R // 2:])))
+    assert np.array_equal(half.tr.buffer(Trainer.BUF_PIXEL), pix[R // 2:])
+    g_sum, sse_sum = half.tr.get_grads()
+    assert sse_sum == pytest.approx(sse_full, rel=1e-5)
+    for off, shape in half.tr.param_slices():
+        n = shape[0] * shape[1]
+        scale = np.abs(g_full[off:off + n]).max()
+        assert np.abs(g_sum[off:off + n] - g_full[off:off + n]).max() <= 2e-5 * scale, shape
+    half.tr.destroy()
+
+    pick = np.sort(np.random.default_rng(1).choice(R, 12, replace=False))
+    X, _ = oracle.batch_from_indices(full.ocams, full.images, idx[pick], S, 2.0, 6.0)
+    m1 = oracle.init_mlp(full.pe, 1024, 512, 12 * S, acc_mode=ACC_F64)
+    m2 = oracle.init_mlp(512, 1024, 4, 12 * S, acc_mode=ACC_F64)
+    a1, a2 = oracle.mlp_arrays(m1), oracle.mlp_arrays(m2)
+    a1["W1"][:], a1["W2"][:], a2["W1"][:], a2["W2"][:] = full.parts
+    buf = oracle.alloc_step(12, S, 16, 8)
+    ref_pix = oracle.render_rays(m1, m2, buf, X)
+    assert np.abs(pix[pick] - ref_pix).max() <= 2e-2
+    oracle.free_step(buf)
+    oracle.free_mlp(m1)
+    oracle.free_mlp(m2)

@@ -21,6 +21,7 @@ echo "pmc pass 3 done"
 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d "$OUT/p4" -o p4 -- python3 "$ROOT/bench.py" $ARGS > "$OUT/p4.log" 2>&1
 echo "pmc pass 4 done"
 cd "$ROOT"
-# bench.py runs its timed batches twice (headline pass, then the pass with per-kernel events): 3 + 10 + 10 steps
-python3 tools/pmc_summary.py "$OUT/pmc_summary.json" steps=23 mfma="$OUT/p1/p1" fetch="$OUT/p2/p2" write="$OUT/p3/p3" sizes="$OUT/p4/p4" > "$OUT/pmc_summary.txt"
+# bench.py's train workload runs its timed batches twice (headline pass, then the pass with per-kernel
+# events): 3 + 10 + 10 steps.  Other workloads: SUMMARY_STEPS=<steps the command runs> (rows per launch position)
+python3 tools/pmc_summary.py "$OUT/pmc_summary.json" steps=${SUMMARY_STEPS:-23} mfma="$OUT/p1/p1" fetch="$OUT/p2/p2" write="$OUT/p3/p3" sizes="$OUT/p4/p4" > "$OUT/pmc_summary.txt"
 tail -5 "$OUT/stats.log"
