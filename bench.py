@@ -204,7 +204,8 @@ def bf16_workload(args, lib, torch):
     import nerf_amd
     from nerf_amd.api import DeviceArray, Trainer, _check, prof_read, synthetic_dataset, trainer_config
     assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "the bf16 workload is single-GPU"
-    rays_total, S, micro, hidden, inter = 1 << 20, 256, 8192, 1024, 512
+    S, micro, hidden, inter = 256, 8192, 1024, 512
+    rays_total = micro * args.micro_batches  # 128 micro-batches = the configuration's 1 048 576 rays per step
     host = synthetic_dataset(num_images=100, width=800, height=800, seed=1234)
     dds = host.upload()
     tr = Trainer(trainer_config(rays_per_batch=micro, num_samples=S, hidden_dim=hidden, intermediate_dim=inter,
@@ -281,6 +282,9 @@ def main():
                     help="train workload only: collapse mlp1's output layer and mlp2's input layer (no activation "
                          "between them) into one product per point, gradients of both derived from it; same "
                          "parameters and results to fp32 rounding, 45 %% fewer FLOPs; reported separately")
+    ap.add_argument("--micro-batches", type=int, default=128,
+                    help="bf16 workload: micro-batches of 8192 rays per optimizer step (128 = the configuration of "
+                         "record; fewer only to keep a counter-collection run short: same kernels, same shapes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="N = 1 train workload: do not append the forward-only render and the bf16 configuration "

@@ -106,7 +106,7 @@ int nerf_weight_gradient_static(const float* d_err, int rows_out, const float* d
  * transpose != 0 writes the transpose ([cols][ld_dst]) */
 int nerf_convert_bf16(const float* d_src, int rows, int cols, int ld_src, unsigned short* d_dst, int ld_dst,
                       int transpose);
-/* C[M][N] = A[M][K] B[N][K]^T, K-contiguous operands; K a multiple of 64, N of 4, lda/ldb of 8, ldc of 4.
+/* C[M][N] = A[M][K] B[N][K]^T, K-contiguous operands; K a multiple of 64, N, lda, ldb and ldc of 8; all pointers 16-byte aligned.
  * epilogue 0: C = product; 1: C = pre-activation (may be NULL), C2 = swish(C); 2: C = product .* swish'(AUX) */
 int nerf_gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, unsigned short* C, int ldc,
                       int M, int N, int K, int epilogue, unsigned short* C2, const unsigned short* AUX);

@@ -115,8 +115,8 @@ struct GemmBf16Args {
     bf16_t* C;          // [M][ldc]: product (EPI_STORE, EPI_DSWISH_MUL) or pre-activation (EPI_SWISH; may be null)
     bf16_t* C2;         // EPI_SWISH: swish of the rounded pre-activation
     const bf16_t* AUX;  // EPI_DSWISH_MUL: pre-activation [M][ldc]
-    int M, N, K;        // K a multiple of 64, N a multiple of 4
-    int lda, ldb, ldc;  // lda, ldb multiples of 8; ldc a multiple of 4
+    int M, N, K;        // K a multiple of 64, N a multiple of 8
+    int lda, ldb, ldc;  // multiples of 8 (rows move in 16-byte pieces)
     int epilogue;
 };
 int gemm_bf16_nt(const GemmBf16Args& args);

@@ -29,6 +29,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BKH = 64;  // bf16 contraction steps per K-tile (128 bytes per k-contiguous row)
 
@@ -118,18 +119,24 @@ __device__ __forceinline__ void nt_store_body(const GemmBf16Args& p, f32x16 (&ac
     const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((EPI == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
     u32x2* stage = reinterpret_cast<u32x2*>(lds_base) + wave * (ROWS * 16);
-    // row-wise view: lane = (row within a group of 4, 8-byte chunk of the line)
-    const int rsub = lane >> 4, cch = lane & 15;
-    const int ncol = n0 + wn * 64 + cch * 4;
-    const unsigned col_off = (ncol + 3 < p.N) ? (unsigned)ncol * 2u : OOR;
+    // row-wise view: lane = (row within a group of 8, 16-byte piece of the line).  The two 8-byte chunks
+    // 2j and 2j+1 of a row share one 16-byte slot under the XOR swizzle (it only permutes them inside
+    // the slot when the row number is odd), so a row goes to or from memory in eight 16-byte pieces:
+    // half as many global instructions as with 8-byte pieces, and it is their issue rate, not the
+    // bytes, that a finished tile waits for.
+    const int rsub = lane >> 3, c16 = lane & 7;
+    const int ncol = n0 + wn * 64 + c16 * 8;
+    const unsigned col_off = (ncol + 7 < p.N) ? (unsigned)ncol * 2u : OOR;
     const unsigned row_bytes = (unsigned)p.ldc * 2u;
+    u32x4* stage16 = reinterpret_cast<u32x4*>(stage);
     if (EPI == EPI_DSWISH_MUL) {
 #pragma unroll 8
-        for (int it = 0; it < ROWS / 4; it++) {
-            const int row = it * 4 + rsub;
+        for (int it = 0; it < ROWS / 8; it++) {
+            const int row = it * 8 + rsub;
             const unsigned voff = col_off == OOR ? OOR : (unsigned)(wm * ROWS + row) * row_bytes + col_off;
-            stage[row * 16 + (cch ^ (row & 15))] =
-                __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rAUX, voff, 0, 0));
+            const u32x4 a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rAUX, voff, 0, 0));
+            const u32x4 sw = {a[2], a[3], a[0], a[1]};
+            stage16[row * 8 + (c16 ^ ((row & 15) >> 1))] = (row & 1) ? sw : a;
         }
     }
 #pragma unroll
@@ -155,16 +162,19 @@ __device__ __forceinline__ void nt_store_body(const GemmBf16Args& p, f32x16 (&ac
         }
     }
 #pragma unroll 8
-    for (int it = 0; it < ROWS / 4; it++) {
-        const int row = it * 4 + rsub;
+    for (int it = 0; it < ROWS / 8; it++) {
+        const int row = it * 8 + rsub;
         const unsigned voff = col_off == OOR ? OOR : (unsigned)(wm * ROWS + row) * row_bytes + col_off;
-        const u32x2 out = stage[row * 16 + (cch ^ (row & 15))];
-        __builtin_amdgcn_raw_buffer_store_b64(out, rC, voff, 0, 0);
+        const u32x4 raw = stage16[row * 8 + (c16 ^ ((row & 15) >> 1))];
+        const u32x4 sw = {raw[2], raw[3], raw[0], raw[1]};
+        const u32x4 out = (row & 1) ? sw : raw;
+        __builtin_amdgcn_raw_buffer_store_b128(out, rC, voff, 0, 0);
         if (EPI == EPI_SWISH) {
             // the activation of the ROUNDED pre-activation: what the backward pass will recompute from
-            const u32x2 act = {pack_bf16(swish_f(bf16_lo(out[0])), swish_f(bf16_hi(out[0]))),
-                               pack_bf16(swish_f(bf16_lo(out[1])), swish_f(bf16_hi(out[1])))};
-            __builtin_amdgcn_raw_buffer_store_b64(act, rC2, voff, 0, 0);
+            u32x4 act;
+#pragma unroll
+            for (int e = 0; e < 4; e++) act[e] = pack_bf16(swish_f(bf16_lo(out[e])), swish_f(bf16_hi(out[e])));
+            __builtin_amdgcn_raw_buffer_store_b128(act, rC2, voff, 0, 0);
         }
     }
 }
@@ -413,10 +423,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int gemm_bf16_nt(const GemmBf16Args& g) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return NERF_ERR_ARG;
-    if (g.K % BKH != 0 || g.N % 4 != 0 || g.lda % 8 != 0 || g.ldb % 8 != 0 || g.ldc % 4 != 0) return NERF_ERR_ARG;
+    if (g.K % BKH != 0 || g.N % 8 != 0 || g.lda % 8 != 0 || g.ldb % 8 != 0 || g.ldc % 8 != 0) return NERF_ERR_ARG;
     if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N) return NERF_ERR_ARG;
-    if (!aligned16(g.A) || !aligned16(g.B) || (reinterpret_cast<uintptr_t>(g.C) & 7) ||
-        (reinterpret_cast<uintptr_t>(g.C2) & 7) || (reinterpret_cast<uintptr_t>(g.AUX) & 7))
+    if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || !aligned16(g.C2) || !aligned16(g.AUX))
         return NERF_ERR_ARG;
     if (g.epilogue != EPI_STORE && g.epilogue != EPI_SWISH && g.epilogue != EPI_DSWISH_MUL) return NERF_ERR_ARG;
     NtArgs ka;

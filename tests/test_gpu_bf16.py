@@ -50,7 +50,7 @@ def test_convert_rounds_to_nearest_even_and_transposes(gpu):
 
 
 # the last three are large enough for the 256x256-tile kernel (>= 256 such tiles), ragged in M and N
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 512, 192), (4096, 512, 512), (130, 1024, 1024), (77, 12, 128),
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 512, 192), (4096, 512, 512), (130, 1024, 1024), (77, 24, 128),
                                    (16500, 1024, 128), (32768, 512, 192), (33000, 520, 64)])
 @pytest.mark.parametrize("epilogue", [0, 1, 2])
 def test_nt_product(gpu, M, N, K, epilogue):
@@ -108,7 +108,7 @@ def test_nt_rejects_unsupported_shapes(gpu):
     d = DeviceArray((256, 256), dtype=np.uint16)
     assert lib.nerf_gemm_bf16_nt(d.ptr, 256, d.ptr, 256, d.ptr, 256, 128, 128, 100, 0, 0, 0) == 1   # K % 64
     assert lib.nerf_gemm_bf16_nt(d.ptr, 250, d.ptr, 256, d.ptr, 256, 128, 128, 128, 0, 0, 0) == 1   # lda % 8
-    assert lib.nerf_gemm_bf16_nt(d.ptr, 256, d.ptr, 256, d.ptr, 256, 128, 126, 128, 0, 0, 0) == 1   # N % 4
+    assert lib.nerf_gemm_bf16_nt(d.ptr, 256, d.ptr, 256, d.ptr, 256, 128, 124, 128, 0, 0, 0) == 1   # N % 8
     assert lib.nerf_gemm_bf16_nt(d.ptr, 256, d.ptr, 256, 0, 256, 128, 128, 128, 0, 0, 0) == 1       # no output
 
 
