@@ -1,15 +1,19 @@
-// gemm_bf16.hip -- matrix products with bf16 operands and fp32 accumulation (v_mfma_f32_32x32x16_bf16)
-// for the reduced-precision configuration of the NeRF hot path (wide MLPs, very large batches).
+// gemm_bf16.hip -- matrix products with bf16 operands and fp32 accumulation for the reduced-precision
+// configuration of the NeRF hot path (wide MLPs, very large batches).
 //
-// Same tiling as the fp32 kernels: 256-thread workgroup, 128x128 output tile, four wavefronts 2x2,
-// each 2x2 MFMA tiles of 32x32 (64 fp32 accumulator registers), operand tiles double-buffered in
-// LDS and filled by LDS-DMA.  A K-tile is 64 contraction steps = 4 MFMA steps of 16.
-//
-//   gemm_bf16_nt_kernel     C[m][n] = sum_k A[m][k] B[n][k], both operands k-contiguous (forward
-//                           layers; data gradients with a transposed copy of the weights).  The
-//                           MFMA computes the TRANSPOSED tile (weights as the row operand): a lane
-//                           then owns 4 consecutive n of one point m, i.e. 8 contiguous bytes of
-//                           the bf16 output row, written with one 8-byte store per 4 accumulators.
+//   gemm_bf16_nt8_kernel    C[m][n] = sum_k A[m][k] B[n][k], both operands k-contiguous (forward
+//                           layers; data gradients with a transposed copy of the weights), for
+//                           products that fill the chip: persistent workgroups of eight wavefronts,
+//                           256x256 tiles, v_mfma_f32_16x16x32_bf16, a four-slot ring of operand
+//                           slices filled by LDS-DMA that runs on across tiles, the two wavefronts
+//                           of a SIMD alternating between matrix instructions and LDS reads.
+//   gemm_bf16_nt_kernel     the same product in the tiling of the fp32 kernels (128x128 tile, four
+//                           wavefronts 2x2, v_mfma_f32_32x32x16_bf16, double-buffered K-tiles of 64
+//                           steps): small products and K < 128.
+//                           Both compute the TRANSPOSED tile (weights as the row operand): a lane then
+//                           owns 4 consecutive n of one point m, i.e. 8 contiguous bytes of the bf16
+//                           output row; finished tiles pass through LDS and leave in 16-byte pieces
+//                           of whole 128-byte lines.
 //   wgrad_bf16_kernel       dW[h][c] = sum_pt Err[pt][h] Act[pt][c]: the contraction index is the
 //                           ROW of both operands.  Tiles are staged row-major ([64 pt][128] bf16)
 //                           and read with ds_read_b64_tr_b16, the hardware transposing LDS read,
@@ -105,78 +109,105 @@ __device__ __forceinline__ void nt_tile(float (&lds)[2][(WM * MI + WN * NI) * 32
 // loads of the pre-activation for the swish' epilogue, which take the same way in the other
 // direction -- moves whole 128-byte lines, 4 rows per instruction.  LDS image: [row][16 chunks of
 // 8 bytes], chunk c of row r at c ^ (r & 15): conflict-free for both access patterns.
+// The three steps of that epilogue.  `stage` is the wavefront's [ROWS][16 chunks of 8 bytes] image.
+struct NtRows {
+    __amdgpu_buffer_rsrc_t rC, rC2, rAUX;
+    unsigned col_off, row_bytes;
+    int row0;  // first row of the wavefront's tile inside the workgroup's panel
+};
+
+template <int EPI>
+__device__ __forceinline__ NtRows nt_rows(const GemmBf16Args& p, int m0, int panel_rows, int row0, int ncol0, int lane) {
+    NtRows r;
+    const int rows_here = (p.M - m0) < panel_rows ? (p.M - m0) : panel_rows;
+    const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 2u;
+    r.rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (size_t)m0 * p.ldc), 0, p.C ? panel_bytes : 0u, 0x00020000);
+    r.rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == EPI_SWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes,
+                                              0x00020000);
+    r.rAUX = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0,
+                                               panel_bytes, 0x00020000);
+    // row-wise view: lane = (row within a group of 8, 16-byte piece of the line).  The two 8-byte chunks
+    // 2j and 2j+1 of a row share one 16-byte slot under the XOR swizzle (it only permutes them inside
+    // the slot when the row number is odd), so a row goes to or from memory in eight 16-byte pieces.
+    const int ncol = ncol0 + (lane & 7) * 8;
+    r.col_off = (ncol + 7 < p.N) ? (unsigned)ncol * 2u : OOR;
+    r.row_bytes = (unsigned)p.ldc * 2u;
+    r.row0 = row0;
+    return r;
+}
+
+// pre-activation rows -> stage (the swish' epilogue reads them from there in the accumulator layout)
+template <int ROWS>
+__device__ __forceinline__ void nt_aux_to_stage(const NtRows& r, u32x2* stage, int lane) {
+    u32x4* stage16 = reinterpret_cast<u32x4*>(stage);
+    const int rsub = lane >> 3, c16 = lane & 7;
+#pragma unroll 8
+    for (int it = 0; it < ROWS / 8; it++) {
+        const int row = it * 8 + rsub;
+        const unsigned voff = r.col_off == OOR ? OOR : (unsigned)(r.row0 + row) * r.row_bytes + r.col_off;
+        const u32x4 a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.rAUX, voff, 0, 0));
+        const u32x4 sw = {a[2], a[3], a[0], a[1]};
+        stage16[row * 8 + (c16 ^ ((row & 15) >> 1))] = (row & 1) ? sw : a;
+    }
+}
+
+// stage -> global rows (and, for the swish epilogue, the activation of the ROUNDED pre-activation:
+// what the backward pass will recompute from)
+template <int ROWS, int EPI>
+__device__ __forceinline__ void nt_stage_to_global(const NtRows& r, const u32x2* stage, int lane) {
+    const u32x4* stage16 = reinterpret_cast<const u32x4*>(stage);
+    const int rsub = lane >> 3, c16 = lane & 7;
+#pragma unroll 8
+    for (int it = 0; it < ROWS / 8; it++) {
+        const int row = it * 8 + rsub;
+        const unsigned voff = r.col_off == OOR ? OOR : (unsigned)(r.row0 + row) * r.row_bytes + r.col_off;
+        const u32x4 raw = stage16[row * 8 + (c16 ^ ((row & 15) >> 1))];
+        const u32x4 sw = {raw[2], raw[3], raw[0], raw[1]};
+        const u32x4 out = (row & 1) ? sw : raw;
+        __builtin_amdgcn_raw_buffer_store_b128(out, r.rC, voff, 0, 0);
+        if (EPI == EPI_SWISH) {
+            u32x4 act;
+#pragma unroll
+            for (int e = 0; e < 4; e++) act[e] = pack_bf16(swish_f(bf16_lo(out[e])), swish_f(bf16_hi(out[e])));
+            __builtin_amdgcn_raw_buffer_store_b128(act, r.rC2, voff, 0, 0);
+        }
+    }
+}
+
+// four consecutive features of one point: accumulators -> (scaled by swish' of the staged
+// pre-activation) -> bf16 -> the point's row in the stage
+template <int EPI>
+__device__ __forceinline__ void nt_put4(u32x2* stage, int row, int c, float v0, float v1, float v2, float v3) {
+    u32x2* slot = stage + row * 16 + (c ^ (row & 15));
+    if (EPI == EPI_DSWISH_MUL) {
+        const u32x2 a = *slot;
+        v0 *= dswish_f(bf16_lo(a[0])); v1 *= dswish_f(bf16_hi(a[0]));
+        v2 *= dswish_f(bf16_lo(a[1])); v3 *= dswish_f(bf16_hi(a[1]));
+    }
+    const u32x2 out = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
+    *slot = out;
+}
+
 template <int WM, int WN, int MI, int NI, int EPI>
 __device__ __forceinline__ void nt_store_body(const GemmBf16Args& p, f32x16 (&acc)[NI][MI], float* lds_base, int m0,
                                               int n0, int wave, int wm, int wn, int lane) {
     static_assert(NI == 2, "a wavefront's tile is 64 features wide");
     constexpr int BM_ = WM * MI * 32, ROWS = MI * 32;
-    const int rows_here = (p.M - m0) < BM_ ? (p.M - m0) : BM_;
-    const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 2u;
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(p.C + (size_t)m0 * p.ldc), 0, p.C ? panel_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((EPI == EPI_SWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rAUX = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((EPI == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+    const NtRows r = nt_rows<EPI>(p, m0, BM_, wm * ROWS, n0 + wn * 64, lane);
     u32x2* stage = reinterpret_cast<u32x2*>(lds_base) + wave * (ROWS * 16);
-    // row-wise view: lane = (row within a group of 8, 16-byte piece of the line).  The two 8-byte chunks
-    // 2j and 2j+1 of a row share one 16-byte slot under the XOR swizzle (it only permutes them inside
-    // the slot when the row number is odd), so a row goes to or from memory in eight 16-byte pieces:
-    // half as many global instructions as with 8-byte pieces, and it is their issue rate, not the
-    // bytes, that a finished tile waits for.
-    const int rsub = lane >> 3, c16 = lane & 7;
-    const int ncol = n0 + wn * 64 + c16 * 8;
-    const unsigned col_off = (ncol + 7 < p.N) ? (unsigned)ncol * 2u : OOR;
-    const unsigned row_bytes = (unsigned)p.ldc * 2u;
-    u32x4* stage16 = reinterpret_cast<u32x4*>(stage);
-    if (EPI == EPI_DSWISH_MUL) {
-#pragma unroll 8
-        for (int it = 0; it < ROWS / 8; it++) {
-            const int row = it * 8 + rsub;
-            const unsigned voff = col_off == OOR ? OOR : (unsigned)(wm * ROWS + row) * row_bytes + col_off;
-            const u32x4 a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rAUX, voff, 0, 0));
-            const u32x4 sw = {a[2], a[3], a[0], a[1]};
-            stage16[row * 8 + (c16 ^ ((row & 15) >> 1))] = (row & 1) ? sw : a;
-        }
-    }
+    if (EPI == EPI_DSWISH_MUL) nt_aux_to_stage<ROWS>(r, stage, lane);
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
         const int row = mi * 32 + (lane & 31);
 #pragma unroll
         for (int ni = 0; ni < NI; ni++) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int c = ni * 8 + 2 * q + (lane >> 5);
-                u32x2* slot = stage + row * 16 + (c ^ (row & 15));
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[ni][mi][4 * q + e];
-                if (EPI == EPI_DSWISH_MUL) {
-                    const u32x2 a = *slot;
-                    v[0] *= dswish_f(bf16_lo(a[0])); v[1] *= dswish_f(bf16_hi(a[0]));
-                    v[2] *= dswish_f(bf16_lo(a[1])); v[3] *= dswish_f(bf16_hi(a[1]));
-                }
-                const u32x2 out = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
-                *slot = out;
-            }
+            for (int q = 0; q < 4; q++)
+                nt_put4<EPI>(stage, row, ni * 8 + 2 * q + (lane >> 5), acc[ni][mi][4 * q], acc[ni][mi][4 * q + 1],
+                             acc[ni][mi][4 * q + 2], acc[ni][mi][4 * q + 3]);
         }
     }
-#pragma unroll 8
-    for (int it = 0; it < ROWS / 8; it++) {
-        const int row = it * 8 + rsub;
-        const unsigned voff = col_off == OOR ? OOR : (unsigned)(wm * ROWS + row) * row_bytes + col_off;
-        const u32x4 raw = stage16[row * 8 + (c16 ^ ((row & 15) >> 1))];
-        const u32x4 sw = {raw[2], raw[3], raw[0], raw[1]};
-        const u32x4 out = (row & 1) ? sw : raw;
-        __builtin_amdgcn_raw_buffer_store_b128(out, rC, voff, 0, 0);
-        if (EPI == EPI_SWISH) {
-            // the activation of the ROUNDED pre-activation: what the backward pass will recompute from
-            u32x4 act;
-#pragma unroll
-            for (int e = 0; e < 4; e++) act[e] = pack_bf16(swish_f(bf16_lo(out[e])), swish_f(bf16_hi(out[e])));
-            __builtin_amdgcn_raw_buffer_store_b128(act, rC2, voff, 0, 0);
-        }
-    }
+    nt_stage_to_global<ROWS, EPI>(r, stage, lane);
 }
 
 // the kind of epilogue is decided once: each body is straight-line code
@@ -237,6 +268,301 @@ __global__ __launch_bounds__(WM * WN * 64, 512 / (WM * WN * 64)) void gemm_bf16_
     if (kt < nkt) nt_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, wm, wn, lane);
 
     nt_store_tile<WM, WN, MI, NI>(p, acc, &lds[0][0], m0, n0, wave, wm, wn, lane);
+}
+
+// ================================================================================================
+// C = A B^T for products large enough to fill the chip: 256x256 tiles, eight wavefronts, a loop in
+// phases
+// ================================================================================================
+// The two wavefronts that share a SIMD take turns: while one issues its 16 matrix instructions the
+// other reads its next fragments from LDS and issues its share of the LDS-DMA.  Workgroup barriers
+// between the phases hold that alternation in step (the second group of four wavefronts runs one
+// barrier behind the first).  The contraction is cut into slices of 32 steps (one
+// v_mfma_f32_16x16x32_bf16 deep): a slice of A and of B is [256 rows][64 bytes] = 16 KB each, four
+// slices live in LDS as a ring (128 KB), and a slice is issued three slices before it is read, so the
+// memory pipe never drains: the waits are counted (vmcnt(8): the two youngest slices may still be in
+// flight), never zero.  Per slice a wavefront (128 points x 64 features) runs two phases: the upper 64
+// points (4 + 4 fragment reads), then the lower 64 (4 reads); each phase is 16 matrix instructions.
+//
+// Ordering of the LDS-DMA writes against the fragment reads (nothing but counted waits and barriers
+// orders them):
+//   read after write : every wavefront waits for its own pieces of slice s+1 in the second phase of
+//                      slice s, before that phase's first barrier; slice s+1 is first read one phase
+//                      later, i.e. behind at least one barrier that every wavefront passed after its wait
+//                      (two for the group that runs ahead);
+//   write after read : slot (s+3)&3 held slice s-1.  Its B half was last read in the first phase of
+//                      slice s-1 and is re-filled in the first phase of slice s; its A half was last
+//                      read in the second phase of s-1 and is re-filled in the second phase of s: two
+//                      phases (four barriers) later, which covers the group that runs one barrier behind.
+// LDS image of a slice: 64-byte rows, the four 16-byte chunks of row r stored at chunk ^ ((r >> 1) & 3)
+// (applied to the source address of the DMA, which writes lanes linearly): the 16 rows x 4 chunks that
+// one fragment read touches then cover all 64 banks once per lane group.
+constexpr int SLICE_BYTES = 256 * 64;  // one operand, one slice
+
+// Where a workgroup's tile lies: buffer descriptors of its 256 rows of A and of B (rows past the
+// matrix fall outside the descriptor and read as zero) and its corner in C.
+struct Nt8Tile {
+    __amdgpu_buffer_rsrc_t a, b;
+    int m0, n0;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const bf16_t* base, int ld, int x0, int X, int K) {
+    const size_t bytes = ((size_t)(X - x0 - 1) * ld + K) * 2;  // from the panel's first element to the end of the matrix
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)x0 * ld), 0,
+                                             (unsigned)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu), 0x00020000);
+}
+
+// tile number -> tile: the column tiles of one row panel are consecutive numbers on one XCD (numbers
+// b and b + 8 share an XCD), so the workgroups that read the same rows of A run side by side
+__device__ __forceinline__ Nt8Tile nt8_tile(const NtArgs& ka, int b) {
+    const GemmBf16Args& p = ka.g;
+    int tm, tn;
+    if ((ka.tiles_m & 7) == 0) {
+        const int slot = b >> 3;
+        tn = slot % ka.tiles_n;
+        tm = (slot / ka.tiles_n) * 8 + (b & 7);
+    } else {
+        tn = b % ka.tiles_n;
+        tm = b / ka.tiles_n;
+    }
+    Nt8Tile t;
+    t.m0 = tm * 256;
+    t.n0 = tn * 256;
+    t.a = panel_rsrc(p.A, p.lda, t.m0, p.M, p.K);
+    t.b = panel_rsrc(p.B, p.ldb, t.n0, p.N, p.K);
+    return t;
+}
+
+// one operand slice by LDS-DMA: 512 threads, 2 pieces of 16 bytes per thread
+__device__ __forceinline__ void slice_issue(__amdgpu_buffer_rsrc_t rsrc, const unsigned (&voff)[2], char* slot, int slice,
+                                            int wave) {
+    const unsigned soff = (unsigned)slice * 64u;
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rsrc, (__attribute__((address_space(3))) void*)(slot + (p * 512 + wave * 64) * 16), 16, voff[p], soff, 0, 0);
+}
+
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+
+// fragment of 16 rows x 32 contraction steps: lane l holds row l & 15, steps 8 (l >> 4) .. +7
+__device__ __forceinline__ bf16x8 slice_frag(const char* slot, unsigned lane_off, int tile) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(slot + lane_off + tile * 1024));
+}
+
+struct Nt8Lane {  // per-thread constants of the loop
+    unsigned voffA[2], voffB[2];  // this thread's pieces of a slice (source offsets, swizzled)
+    unsigned offA, offB;          // this lane's place in the wavefront's fragments
+    int wave;
+};
+
+// One slice.  SLOT: its ring slot (compile-time, so every LDS address is a register plus an
+// immediate).  The slice issued into slot SLOT+3 is slice `next` of this tile or, past its end, slice
+// next - ns of the workgroup's NEXT tile: the ring runs on across tiles.
+// VM: how many vector-memory operations may still be outstanding when this wavefront's pieces of the
+// next slice to be read must have landed.  Vector-memory operations of one wavefront complete in the
+// order issued, loads and stores alike (the compiler's own counted waits rest on the same rule), and a
+// slice is 4 loads per wavefront: in the steady state the two youngest slices may be in flight, VM = 8.
+// The first two slices of a tile follow the S stores of the previous tile's epilogue, which were
+// issued after the slices they wait for: VM = 8 + S lets those stores stay in flight instead of
+// holding the loop until the memory system has acknowledged them.
+template <int SLOT, int VM>
+__device__ __forceinline__ void nt8_slice(char* lds, const Nt8Tile& cur, const Nt8Tile& nxt, int next, int ns,
+                                          const Nt8Lane& L, f32x4acc (&acc)[4][8]) {
+    static_assert(VM >= 8 && VM < 64, "vmcnt is a 6-bit field");
+    const char* SA = lds + SLOT * SLICE_BYTES;
+    const char* SB = lds + 4 * SLICE_BYTES + SLOT * SLICE_BYTES;
+    char* NA = lds + ((SLOT + 3) & 3) * SLICE_BYTES;
+    char* NB = lds + 4 * SLICE_BYTES + ((SLOT + 3) & 3) * SLICE_BYTES;
+    const bool wrap = next >= ns;
+    const __amdgpu_buffer_rsrc_t ra = wrap ? nxt.a : cur.a, rb = wrap ? nxt.b : cur.b;
+    const int slice = wrap ? next - ns : next;
+    bf16x8 fx[4], fw[4];
+    // ---- phase 1: upper 64 points -------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; i++) fw[i] = slice_frag(SB, L.offB, i);
+#pragma unroll
+    for (int i = 0; i < 4; i++) fx[i] = slice_frag(SA, L.offA, i);
+    slice_issue(rb, L.voffB, NB, slice, L.wave);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+            acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fx[mi], acc[ni][mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: lower 64 points -------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; i++) fx[i] = slice_frag(SA, L.offA, 4 + i);
+    slice_issue(ra, L.voffA, NA, slice, L.wave);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+            acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fx[mi], acc[ni][4 + mi], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+}
+
+// stores per wavefront in the epilogue of one tile: 4 passes of 4 rows-of-lines, twice that when the
+// activation is written beside the pre-activation
+template <int EPI>
+constexpr int nt8_stores() { return EPI == EPI_SWISH ? 32 : 16; }
+
+// A finished tile leaves through the wavefront's own 4 KB of LDS beside the ring, 32 points at a time
+// (the ring keeps running underneath: the next tile's first slices are landing meanwhile).  The
+// pre-activation rows of the swish' epilogue are fetched one pass ahead, before the stores of the pass
+// in hand: waiting for a load also waits for everything issued before it, and that way a pass never
+// waits for its predecessor's stores.
+template <int EPI>
+__device__ __forceinline__ void nt8_store(const GemmBf16Args& p, f32x4acc (&acc)[4][8], char* stage_base, int m0, int n0,
+                                          int wm, int wn, int lane_id) {
+    // Everything per-lane below is derived again for every tile (a handful of integer instructions):
+    // carried through the loop of slices as loop invariants, these values would not fit beside the
+    // accumulators and would come back from scratch memory -- vector-memory loads, in this of all places.
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    const NtRows r = nt_rows<EPI>(p, m0, 256, wm * 128, n0 + wn * 64, lane);
+    u32x2* stage = reinterpret_cast<u32x2*>(stage_base);
+    u32x4* stage16 = reinterpret_cast<u32x4*>(stage_base);
+    const int rsub = lane >> 3, c16 = lane & 7;
+    u32x4 aux[4];
+    auto fetch_aux = [&](int q) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = q * 32 + it * 8 + rsub;
+            const unsigned voff = r.col_off == OOR ? OOR : (unsigned)(r.row0 + row) * r.row_bytes + r.col_off;
+            aux[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.rAUX, voff, 0, 0));
+        }
+    };
+    if (EPI == EPI_DSWISH_MUL) fetch_aux(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (EPI == EPI_DSWISH_MUL) {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int row = it * 8 + rsub;
+                const u32x4 a = aux[it];
+                const u32x4 sw = {a[2], a[3], a[0], a[1]};
+                stage16[row * 8 + (c16 ^ ((row & 15) >> 1))] = (row & 1) ? sw : a;
+            }
+            if (q < 3) fetch_aux(q + 1);
+        }
+        // accumulator tile (ni, mi): lane l holds point 16 mi + (l & 15), features 16 ni + 4 (l >> 4) + (0..3)
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+                nt_put4<EPI>(stage, h * 16 + (lane & 15), ni * 4 + (lane >> 4), acc[ni][2 * q + h][0], acc[ni][2 * q + h][1],
+                             acc[ni][2 * q + h][2], acc[ni][2 * q + h][3]);
+        NtRows rq = r;
+        rq.row0 = wm * 128 + q * 32;
+        nt_stage_to_global<32, EPI>(rq, stage, lane);
+    }
+}
+
+// the slices of one tile, ring slots START, START+1, ... (START is 0, or 2 when the slice count of
+// the tiles before it was not a multiple of 4); S: the stores issued since slices 1 and 2 were
+template <int START, int S>
+__device__ __forceinline__ void nt8_tile_loop(char* lds, const Nt8Tile& cur, const Nt8Tile& nxt, int ns, const Nt8Lane& L,
+                                              f32x4acc (&acc)[4][8]) {
+    // the first four slices (ns >= 4)
+    nt8_slice<(START + 0) & 3, 8 + S>(lds, cur, nxt, 3, ns, L, acc);
+    nt8_slice<(START + 1) & 3, 8 + S>(lds, cur, nxt, 4, ns, L, acc);
+    nt8_slice<(START + 2) & 3, 8>(lds, cur, nxt, 5, ns, L, acc);
+    nt8_slice<(START + 3) & 3, 8>(lds, cur, nxt, 6, ns, L, acc);
+    int s = 4;
+    for (; s + 4 <= ns; s += 4) {
+        nt8_slice<(START + 0) & 3, 8>(lds, cur, nxt, s + 3, ns, L, acc);
+        nt8_slice<(START + 1) & 3, 8>(lds, cur, nxt, s + 4, ns, L, acc);
+        nt8_slice<(START + 2) & 3, 8>(lds, cur, nxt, s + 5, ns, L, acc);
+        nt8_slice<(START + 3) & 3, 8>(lds, cur, nxt, s + 6, ns, L, acc);
+    }
+    if (s < ns) {  // two slices left
+        nt8_slice<(START + 0) & 3, 8>(lds, cur, nxt, s + 3, ns, L, acc);
+        nt8_slice<(START + 1) & 3, 8>(lds, cur, nxt, s + 4, ns, L, acc);
+    }
+}
+
+// Persistent: workgroup w takes tiles w, w + gridDim.x, ...  (gridDim.x a multiple of 8, so a
+// workgroup stays on the tiles of one XCD's share).
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_nt8_kernel(const NtArgs ka) {
+    __shared__ __attribute__((aligned(16))) char lds[8 * SLICE_BYTES + 8 * 4096];  // A ring, B ring, stages
+    const GemmBf16Args& p = ka.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = ka.tiles_m * ka.tiles_n;
+    const int ns = p.K / 32;  // slices per tile; K is a multiple of 64 and at least 128: even, >= 4
+
+    Nt8Lane L;
+    L.wave = wave;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int piece = q * 512 + tid;
+        const int row = piece >> 2, chunk = (piece & 3) ^ ((row >> 1) & 3);
+        L.voffA[q] = (unsigned)(row * p.lda + chunk * 8) * 2u;
+        L.voffB[q] = (unsigned)(row * p.ldb + chunk * 8) * 2u;
+    }
+    {   // this lane's place in a 16-row fragment; the wavefront's rows: points wm*128.., features wn*64..
+        const int frow = lane & 15;
+        const unsigned frag_off = (unsigned)(frow * 64 + (((lane >> 4) ^ ((frow >> 1) & 3)) * 16));
+        L.offA = frag_off + (unsigned)(wm * 128 * 64);
+        L.offB = frag_off + (unsigned)(wn * 64 * 64);
+    }
+    char* stage = lds + 8 * SLICE_BYTES + wave * 4096;
+
+    int t = blockIdx.x;
+    Nt8Tile cur = nt8_tile(ka, t);
+    // slices 0, 1, 2 of the first tile (B then A each, the order the loop issues them in)
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        slice_issue(cur.b, L.voffB, lds + 4 * SLICE_BYTES + s * SLICE_BYTES, s, wave);
+        slice_issue(cur.a, L.voffA, lds + s * SLICE_BYTES, s, wave);
+    }
+    // all three landed (no stores precede the first tile, so its first slices cannot count on the
+    // order of completion the way later tiles do)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int start = 0;
+    for (; t < ntiles; t += gridDim.x) {
+        // the tile after this one; after the last, this tile again (its slices are fetched into the
+        // ring once more and never read)
+        const int tn = t + (int)gridDim.x < ntiles ? t + (int)gridDim.x : t;
+        const Nt8Tile nxt = nt8_tile(ka, tn);
+        f32x4acc acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+        if (wm == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind through the loop
+        if (start == 0) nt8_tile_loop<0, nt8_stores<EPI>()>(lds, cur, nxt, ns, L, acc);
+        else nt8_tile_loop<2, nt8_stores<EPI>()>(lds, cur, nxt, ns, L, acc);
+        if (wm == 0) __builtin_amdgcn_s_barrier();  // the first group makes up the barrier it is ahead by
+        start = (start + ns) & 3;
+
+        nt8_store<EPI>(p, acc, stage, cur.m0, cur.n0, wm, wn, lane);
+        cur = nxt;
+    }
+    // the re-fetched slices of the last tile are still landing in the ring: let them, before the LDS
+    // is handed back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ================================================================================================
@@ -438,7 +764,18 @@ int gemm_bf16_nt(const GemmBf16Args& g) {
     ka.tiles_n = (g.N + tile - 1) / tile;
     const long grid = (long)ka.tiles_m * ka.tiles_n;
     if (grid > 0x7fffffffL) return NERF_ERR_ARG;
-    if (big)
+    if (big && g.K >= 128) {
+        // persistent: one workgroup per CU (a multiple of 8 of them, so each stays on one XCD's tiles)
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        long wgs = (cus / 8) * 8;
+        if (wgs < 8) wgs = 8;
+        if (wgs > grid) wgs = grid;
+        const dim3 gr((unsigned)wgs), bl(512);
+        if (g.epilogue == EPI_SWISH) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_SWISH>, gr, bl, 0, stream(), ka);
+        else if (g.epilogue == EPI_DSWISH_MUL) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_DSWISH_MUL>, gr, bl, 0, stream(), ka);
+        else hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_STORE>, gr, bl, 0, stream(), ka);
+    } else if (big)
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 4, 4, 2>), dim3((unsigned)grid), dim3(512), 0, stream(), ka);
     else
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 2, 2, 2>), dim3((unsigned)grid), dim3(256), 0, stream(), ka);
