@@ -49,9 +49,12 @@ def test_convert_rounds_to_nearest_even_and_transposes(gpu):
     assert np.array_equal(gt[:, :37], to_bf16_bits(x).T) and not gt[:, 37:].any()
 
 
-# the last three are large enough for the 256x256-tile kernel (>= 256 such tiles), ragged in M and N
+# The last five are large enough for the 256x256-tile kernels (>= 256 such tiles), ragged in M and N.  The
+# last two give every persistent workgroup several tiles with a slice count that is not a multiple of
+# the ring's four slots (K = 192: 6 slices, K = 320: 10), so consecutive tiles start in different slots.
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 512, 192), (4096, 512, 512), (130, 1024, 1024), (77, 24, 128),
-                                   (16500, 1024, 128), (32768, 512, 192), (33000, 520, 64)])
+                                   (16500, 1024, 128), (32768, 512, 192), (33000, 520, 64), (70000, 512, 192),
+                                   (66000, 1032, 320)])
 @pytest.mark.parametrize("epilogue", [0, 1, 2])
 def test_nt_product(gpu, M, N, K, epilogue):
     from nerf_amd._lib import lib
@@ -82,12 +85,13 @@ def test_nt_product(gpu, M, N, K, epilogue):
         assert np.array_equal(d_C3.numpy(), d_C2.numpy())
 
 
-def test_nt_product_with_pitched_rows(gpu):
+@pytest.mark.parametrize("M,N", [(300, 256), (22100, 520)])  # the second: the 256x256-tile kernel
+def test_nt_product_with_pitched_rows(gpu, M, N):
     """operands and result with row pitches larger than their widths (the trainer's padded encoding)"""
     from nerf_amd._lib import lib
     from nerf_amd.api import DeviceArray
     rng = np.random.default_rng(5)
-    M, N, K, lda, ldb, ldc = 300, 256, 192, 200, 192, 264
+    K, lda, ldb, ldc = 192, 200, 192, N + 8
     A = np.zeros((M, lda), np.uint16)
     A[:, :K] = to_bf16_bits(rng.normal(size=(M, K)))
     A[:, K:] = 0x7FC0  # NaN patterns outside the K range must never be read into the product
