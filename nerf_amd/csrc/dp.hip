@@ -15,6 +15,7 @@
 #include "../../include/nerf_amd.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
 #include <string.h>
 #include <time.h>
@@ -47,8 +48,13 @@ std::mutex g_rccl_mutex;
 const Rccl* rccl() {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle) return &g_rccl;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // A copy the process already holds (PyTorch ships its own) is shared.  Otherwise the system's is
+    // loaded with local scope: its symbols must not capture the calls of a second copy that arrives
+    // later with its own users (two RCCL builds resolving into each other end in a corrupted heap).
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) {
         fprintf(stderr, "nerf_dp: cannot load librccl.so.1 (%s)\n", dlerror());
         return nullptr;
@@ -107,7 +113,8 @@ NerfDp* nerf_dp_init(int rank, int world, const unsigned char* id) {
 }
 
 // The id travels through a file: rank 0 creates it (written under a temporary name and renamed, so a
-// reader never sees half of it), the other ranks wait for the file to appear.  ncclCommInitRank returns
+// reader never sees half of it), the other ranks wait until the file holds a whole id (a caller may
+// have reserved the name with an empty file).  ncclCommInitRank returns
 // once every rank has joined, after which rank 0 removes the file.
 NerfDp* nerf_dp_init_from_file(int rank, int world, const char* path, int timeout_seconds) {
     if (!path || world < 1 || rank < 0 || rank >= world) return nullptr;
@@ -116,11 +123,18 @@ NerfDp* nerf_dp_init_from_file(int rank, int world, const char* path, int timeou
         if (nerf_dp_unique_id(id) != NERF_OK) return nullptr;
         char tmp[1024];
         snprintf(tmp, sizeof(tmp), "%s.tmp", path);
-        FILE* f = fopen(tmp, "wb");
-        if (!f) { fprintf(stderr, "nerf_dp: cannot write %s\n", tmp); return nullptr; }
+        // a new file of this process only: never through a link someone left under that name
+        const int fd = open(tmp, O_CREAT | O_EXCL | O_WRONLY, 0600);
+        FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;
+        if (!f) {
+            if (fd >= 0) close(fd);
+            fprintf(stderr, "nerf_dp: cannot write %s\n", tmp);
+            return nullptr;
+        }
         const bool wrote = fwrite(id, 1, sizeof(id), f) == sizeof(id);
         if (fclose(f) != 0 || !wrote || rename(tmp, path) != 0) {
             fprintf(stderr, "nerf_dp: cannot publish %s\n", path);
+            unlink(tmp);
             return nullptr;
         }
     } else {

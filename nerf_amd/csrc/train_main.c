@@ -215,7 +215,15 @@ int main(int argc, char** argv) {
         fprintf(stderr, "--ranks needs --path fused\n");
         return -1;
     }
-    if (o.ranks > 0) snprintf(id_path, sizeof(id_path), "/tmp/nerf_dp_%ld.id", (long)getpid());
+    if (o.ranks > 0) { /* a name of this run's own; the file stays empty until rank 0 publishes the id */
+        snprintf(id_path, sizeof(id_path), "/tmp/nerf_dp_XXXXXX");
+        const int fd = mkstemp(id_path);
+        if (fd < 0) {
+            perror("mkstemp");
+            return -1;
+        }
+        close(fd);
+    }
     fflush(NULL);
     for (int r = 1; r < world; r++) {
         const pid_t p = fork();
@@ -239,6 +247,7 @@ int main(int argc, char** argv) {
         dp = nerf_dp_init_from_file(rank, world, id_path, 120);
         if (!dp) {
             fprintf(stderr, "rank %d: failed to join the communicator\n", rank);
+            if (rank == 0) unlink(id_path);
             return -1;
         }
     }

@@ -573,10 +573,11 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
 // Device buffers of the renderer, kept between calls (a trainer that renders every few thousand
 // steps would otherwise allocate and free gigabytes per picture): forward-only views of the two MLPs
 // for one chunk of rays, the chunk's encoding, the re-pitched layer-1 weights, the fused pair's
-// matrix and the picture.  Rebuilt when the chunk size or a width changes; nerf_render_release()
+// matrix and the picture.  Rebuilt when the chunk size, a width or the current GPU changes; nerf_render_release()
 // frees them.
 namespace {
 struct RenderCache {
+    int dev;  // the GPU the buffers live on
     int N, in1, H1, mid, H2, out2, pe_ld;
     size_t pixels;  // capacity of d_pixel / d_rgb8 in pixels
     MLP *r1, *r2;
@@ -596,11 +597,14 @@ void render_cache_free() {
 // makes g_render fit this call; NERF_OK or NERF_ERR_HIP (then the cache is empty)
 int render_cache_prepare(const MLP* mlp1, const MLP* mlp2, int N, int pe_ld, size_t total) {
     RenderCache& c = g_render;
-    const bool same = c.r1 && c.N == N && c.in1 == mlp1->input_dim && c.H1 == mlp1->hidden_dim &&
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return NERF_ERR_HIP;
+    const bool same = c.r1 && c.dev == dev && c.N == N && c.in1 == mlp1->input_dim && c.H1 == mlp1->hidden_dim &&
                       c.mid == mlp1->output_dim && c.H2 == mlp2->hidden_dim && c.out2 == mlp2->output_dim &&
                       c.pe_ld == pe_ld;
     if (!same) {
         render_cache_free();
+        c.dev = dev;
         c.N = N; c.in1 = mlp1->input_dim; c.H1 = mlp1->hidden_dim; c.mid = mlp1->output_dim;
         c.H2 = mlp2->hidden_dim; c.out2 = mlp2->output_dim; c.pe_ld = pe_ld;
         // forward-only views: the weight pointers are set per call (the reference clones the weights
