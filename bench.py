@@ -146,6 +146,50 @@ def cpu_baseline(seconds=12.0, rays=64, samples=128):
     return out
 
 
+def optin_train_rate(lib, host, dds, R, S, steps, warmup, split, fused):
+    """The headline's step on the same synthetic scene with this library's opt-in arithmetic -- split-bf16
+    matrix products and/or the activation-free layer pair run as one product -- timed like the headline
+    (ray indices resident, one synchronisation on either side of `steps` steps).  Same parameters, same
+    fp32 storage; both pass the headline's parity bars.  Never the benchmark of record."""
+    import numpy as np
+    import torch
+    import nerf_amd
+    from nerf_amd.api import DeviceArray, Trainer, trainer_config
+    cfg = trainer_config(rays_per_batch=R, num_samples=S, precision=2 if split else 0, fuse_linear_pair=int(fused))
+    tr = Trainer(cfg)
+    tr.init_weights(seed=1, use_rand=False)
+    ctypes.CDLL("libc.so.6").srand(1000)
+    idx = np.concatenate([host.draw_ray_indices(R) for _ in range(warmup + steps)], axis=0)
+    d_idx = DeviceArray.from_numpy(idx)
+    stride = R * 3 * 4
+
+    def run(first, count):
+        for s in range(first, first + count):
+            nerf_amd.api._check(lib.nerf_trainer_step(tr.handle, dds.handle, d_idx.ptr + s * stride, 0), "step")
+        torch.cuda.synchronize()
+
+    run(0, warmup)
+    t0 = time.perf_counter()
+    run(warmup, steps)
+    elapsed = time.perf_counter() - t0
+    out = {
+        "metric": "trained rays/s @128 samples/ray",
+        "value": R * steps / elapsed,
+        "unit": "rays/s",
+        "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps,
+        "warmup": warmup,
+        "dtype": "f32 storage and accumulation, split-bf16 products" if split else "f32",
+        "config": {"workload": f"the headline's training step, {R} rays x {S} samples, opt-in: "
+                               + " + ".join((["split-bf16 matrix products (three bf16 MFMA products per fp32 product)"]
+                                             if split else []) + (["linear pair fused (45 % fewer FLOPs)"] if fused else []))},
+        "executed_flop_per_point": 1892352.0 if fused else 3465216.0,
+        "final_loss_per_ray": tr.last_loss(),
+    }
+    tr.destroy()
+    return out
+
+
 def render_workload(args, lib, torch):
     """nerf_render_view on one 800x800 view (640 000 rays x 128 samples, 98.8 TFLOP of products): the
     whole call, including its buffer allocation and the D2H copy of the image."""
@@ -287,8 +331,9 @@ def main():
                          "record; fewer only to keep a counter-collection run short: same kernels, same shapes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="N = 1 train workload: do not append the forward-only render and the bf16 configuration "
-                         "(each a short run of its own after the headline has been timed) as `secondary`")
+                    help="N = 1 train workload: do not append `secondary` (short runs of their own after the headline "
+                         "has been timed: the step with the opt-in arithmetic modes, the forward-only render and "
+                         "the bf16 configuration)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on device 0 with the gloo backend: exercises the multi-rank code path "
                          "on a one-GPU box (RCCL refuses two ranks on one device); the number is meaningless")
@@ -510,14 +555,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(seconds=args.cpu_seconds)
         if world == 1 and not args.no_secondary and not split and not fused and (R, S) == (4096, 128):
-            # the two other single-GPU configurations the baseline names, each a short run of its own
-            # after the headline (their numbers never enter `value`)
+            # after the headline, short runs of their own whose numbers never enter `value`: the step with
+            # the library's opt-in arithmetic, and the two other single-GPU configurations the baseline names
             tr.destroy()
-            dds.release()
             del params, grads, d_idx
+            out["secondary"] = {}
+            for key, sp, fu in (("train_split_bf16_products", True, False), ("train_linear_pair_fused", False, True),
+                                ("train_split_bf16_products_linear_pair_fused", True, True)):
+                out["secondary"][key] = optin_train_rate(lib, host, dds, R, S, 20, 5, sp, fu)
+            dds.release()
             sec_args = argparse.Namespace(**vars(args))
             sec_args.rays, sec_args.samples, sec_args.steps, sec_args.warmup = 4096, 128, 3, 1
-            out["secondary"] = {"render_800x800_fp32": render_workload(sec_args, lib, torch)}
+            out["secondary"]["render_800x800_fp32"] = render_workload(sec_args, lib, torch)
             lib.nerf_render_release()
             sec_args.steps = 2
             out["secondary"]["bf16_1M_rays_x_256_width_1024"] = bf16_workload(sec_args, lib, torch)

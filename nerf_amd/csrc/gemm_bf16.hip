@@ -759,7 +759,9 @@ int gemm_bf16_nt(const GemmBf16Args& g) {
     // the 256x256 shape when the product is large enough to fill the chip with it
     const bool big = g.N > 128 && (long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 256;
     const int tile = big ? 256 : 128;
-    if ((long long)tile * g.ldc * 2 > 0x7fffffffLL) return NERF_ERR_ARG;
+    // a tile's rows of A, B and C are addressed with 32-bit byte offsets from the tile's first row
+    const int ld_max = g.lda > g.ldb ? (g.lda > g.ldc ? g.lda : g.ldc) : (g.ldb > g.ldc ? g.ldb : g.ldc);
+    if ((long long)tile * ld_max * 2 > 0x7fffffffLL) return NERF_ERR_ARG;
     ka.tiles_m = (g.M + tile - 1) / tile;
     ka.tiles_n = (g.N + tile - 1) / tile;
     const long grid = (long)ka.tiles_m * ka.tiles_n;
