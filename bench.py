@@ -373,7 +373,24 @@ def main():
     lib.nerf_set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     # N > 1 on GPUs: the gradient all-reduce is the library's own RCCL call (nerf_dp_*); the torch
     # process group only carries the communicator id and the barriers around the timed region
-    group = dp.RcclGroup() if world > 1 and not args.rehearse_on_one_gpu else None
+    group, collective = None, "none (one rank)"
+    if world > 1 and args.rehearse_on_one_gpu:
+        collective = "gloo through a host copy (rehearsal)"
+    elif world > 1:
+        try:
+            group = dp.RcclGroup()
+        except Exception as e:  # noqa: BLE001  (reported below; every rank must learn of it)
+            print(f"[rank {rank}] nerf_dp communicator failed: {e}", file=sys.stderr, flush=True)
+        # all ranks take the same road: the library's communicator only if every rank has one
+        ok = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if group is not None:
+                group.destroy()
+            group = None
+            collective = "torch.distributed all_reduce (RCCL); the library's own communicator could not be set up"
+        else:
+            collective = "nerf_dp_allreduce_sum (RCCL through the library's C entry points)"
 
     if args.workload == "render":
         print(json.dumps(render_workload(args, lib, torch)), flush=True)
@@ -546,6 +563,7 @@ def main():
                 "global_rays": R * world,
                 "samples_per_ray": S,
                 "parallelism": f"dp{world}",
+                "collective": collective,
                 "device": info["name"],
                 "compute_units": info["compute_units"],
             },
