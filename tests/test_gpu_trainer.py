@@ -207,13 +207,15 @@ def test_create_rejects_bad_config(gpu):
         assert not lib.nerf_trainer_create(C.byref(cfg), 0, 0)
 
 
-def test_full_size_step_properties(gpu, oracle_fast):
-    """The benchmark configuration at full size (4096 rays x 128 samples, 150-512-512-512-4), where the
-    oracle's whole step is too slow to run: additivity over ray shards, reproducibility, and the
-    oracle on a scattered subset of rays (rays are independent in the forward pass)."""
+@pytest.mark.parametrize("R", [4096, 8192])
+def test_full_size_step_properties(gpu, oracle_fast, R):
+    """The benchmark configuration at full size (4096 rays x 128 samples, 150-512-512-512-4) and one GPU's
+    share of the 65 536-ray data-parallel batch on 8 GPUs (8192 rays), where the oracle's whole step is
+    too slow to run: additivity over ray shards, reproducibility, and the oracle on a scattered subset of
+    rays (rays are independent in the forward pass)."""
     from oracle.pyoracle import ACC_F64
     from nerf_amd.api import DeviceArray, Trainer
-    R, S = 4096, 128
+    S = 128
     full = Pair(gpu, oracle_fast, R, S, n_images=4)       # the oracle side of this Pair is not stepped
     idx = full.indices(2024)
     d_idx = DeviceArray.from_numpy(idx)
