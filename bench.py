@@ -538,6 +538,19 @@ def main():
             "gemm_share_of_step": all_ms / (elapsed_events * 1e3),
             "kernels": kernels,
         }
+        if world == 1 and not args.no_secondary:
+            # the compositing kernels at batch sizes where a launch is more than its own start-up (at the
+            # headline's 4096 rays they run 4-5 us each): synthetic network output, timed on their own
+            from tools.composite_bench import measure as composite_measure
+            roofline["composite_at_scale"] = []
+            for rays_c in (8192, 65536, 524288):
+                m = composite_measure(rays_c, S)
+                m["forward_frac_of_hbm_peak"] = m["forward_gbs"] / PEAK_HBM_GBS
+                m["gradient_frac_of_hbm_peak"] = m["gradient_gbs"] / PEAK_HBM_GBS
+                roofline["composite_at_scale"].append(m)
+            roofline["composite_at_scale_note"] = ("16 B per sample read (+16 B written by the gradient) against "
+                                                   "8 TB/s; the 65 536-ray batch (134 MB) fits the 256 MB Infinity "
+                                                   "Cache, the 524 288-ray batch (1 GB) does not")
         info = nerf_amd.api.device_info()
         out = {
             "metric": "trained rays/s @128 samples/ray",
