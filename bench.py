@@ -286,6 +286,19 @@ def bf16_workload(args, lib, torch):
     all_work = sum(v[2] for v in gemm.values())
     dom = max(gemm, key=lambda k: gemm[k][0])
     achieved = gemm[dom][2] / (gemm[dom][0] * 1e-3) / 1e12
+    labels = {
+        "gemm_fwd": "gemm_bf16_nt8_kernel<swish / store> (forward layers: v_mfma_f32_16x16x32_bf16, persistent 256x256 "
+                    "tiles, four-slot LDS-DMA ring of 32-step slices)",
+        "gemm_dgrad": "gemm_bf16_nt8_kernel<store / swish'> (data gradients: the same kernel on transposed weight copies)",
+        "gemm_wgrad": "wgrad_bf16_kernel<2, 4, 4, 2> (v_mfma_f32_32x32x16_bf16, 256x256 tiles, ds_read_b64_tr_b16 operands)",
+    }
+    # HBM side of the same products: operands read once, results written once, per point of a micro-batch
+    # (bf16, 2 bytes): enc->pre1,act1; act1->y1; y1->pre2,act2; eh2->dy1; dy1 (+pre1)->eh1; three weight gradients
+    pe_ld = 192
+    elems_per_point = ((pe_ld + 2 * hidden) + (hidden + inter) + (inter + 2 * hidden) + (hidden + inter)
+                       + (inter + 2 * hidden) + 2 * (hidden + inter) + (hidden + pe_ld))
+    product_bytes = 2.0 * elems_per_point * micro * S * n_micro * steps
+    traffic, _, traffic_file = pmc_traffic("gemm_bf16_nt8_kernel<1>", "bf16_cfg5_")
     out = ({
         "metric": "trained rays/s @256 samples/ray, bf16 operands", "value": rays_total * steps / el, "unit": "rays/s",
         "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": el / steps * 1e3,
@@ -294,9 +307,20 @@ def bf16_workload(args, lib, torch):
         "config": {"workload": f"{rays_total} rays x {S} samples per optimizer step in {n_micro} micro-batches of "
                                f"{micro} rays, MLP 150-{hidden}-{inter}-{hidden}-4"},
         "final_loss_per_ray": tr.last_loss() * micro / rays_total,
-        "roofline": {"bound": "mfma", "kernel": f"bf16 products ({dom}: v_mfma_f32_32x32x16_bf16)", "achieved": achieved,
-                     "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0, "traffic": None,
+        "roofline": {"bound": "mfma", "kernel": labels.get(dom, dom), "achieved": achieved,
+                     "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
+                     "traffic": traffic,
+                     "traffic_unit": "HBM-side bytes per launch of gemm_bf16_nt8_kernel<swish> (L2 fetches x2 + writes), "
+                                     "average of its two positions in a micro-batch",
+                     "traffic_source": traffic_file and f"{traffic_file}: counters of an earlier run of this workload",
                      "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12, "gemm_share_of_step": all_ms / (el * 1e3),
+                     "products_against_hbm": {
+                         "bound": "hbm", "achieved": product_bytes / (all_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": product_bytes / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "algorithmic_bytes_per_point": 2.0 * elems_per_point,
+                         "flop_per_byte": all_work / product_bytes,
+                         "note": "these products sit between the roofs: about 236 FLOP per byte against a machine "
+                                 "balance of about 400 (2.5 PFLOP/s over 6.3 TB/s a copy reaches)"},
                      "kernels": {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in prof.items()
                                  if v[1] > 0}},
     })
