@@ -234,7 +234,10 @@ def render_workload(args, lib, torch):
                                + (", linear pair fused (opt-in)" if fused else "")},
         "roofline": {"bound": "mfma", "kernel": kernel,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": None,
+                     "frac": achieved / peak,
+                     "traffic": None if (split or fused) else pmc_traffic(GEMM_KERNEL["gemm_fwd"], "render_")[0],
+                     "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of an earlier run "
+                                     "of this workload, profiles/rNN_render_pmc_summary.json)",
                      "gemm_share_of_step": ms / (el * 1e3)},
         "mean_byte": float(np.mean(rgb8)),
     })
