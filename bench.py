@@ -406,18 +406,19 @@ def main():
     elif world > 1:
         try:
             group = dp.RcclGroup()
-        except Exception as e:  # noqa: BLE001  (reported below; every rank must learn of it)
+        except Exception as e:  # noqa: BLE001  (every rank must learn of it before any rank leaves)
             print(f"[rank {rank}] nerf_dp communicator failed: {e}", file=sys.stderr, flush=True)
-        # all ranks take the same road: the library's communicator only if every rank has one
+        # there is one collective path: if any rank has no communicator of the library's, the run fails on
+        # every rank, loudly -- nothing falls back to another all-reduce
         ok = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             if group is not None:
                 group.destroy()
-            group = None
-            collective = "torch.distributed all_reduce (RCCL); the library's own communicator could not be set up"
-        else:
-            collective = "nerf_dp_allreduce_sum (RCCL through the library's C entry points)"
+            dist.destroy_process_group()
+            raise SystemExit(f"[rank {rank}] the library's RCCL communicator (nerf_dp_*) could not be set up on every "
+                             "rank: no result")
+        collective = "nerf_dp_allreduce_sum (RCCL through the library's C entry points)"
 
     if args.workload == "render":
         print(json.dumps(render_workload(args, lib, torch)), flush=True)
@@ -445,8 +446,11 @@ def main():
 
     total_steps = args.warmup + args.steps
     libc = ctypes.CDLL("libc.so.6")
-    libc.srand(1000 + rank)  # every rank draws its own rays (nerf.c:168-173 order)
-    idx = np.concatenate([host.draw_ray_indices(R) for _ in range(total_steps)], axis=0)
+    # every rank seeds alike, draws the GLOBAL batch of world x R rays in the reference's order
+    # (nerf.c:168-173) and keeps its contiguous block [rank x R, (rank + 1) x R): N ranks train on exactly
+    # the rays one rank would train on with a batch of N x R (with N = 1 this is nerf_draw_ray_indices)
+    libc.srand(1000)
+    idx = np.concatenate([host.draw_ray_indices_shard(R * world, rank, world) for _ in range(total_steps)], axis=0)
     d_idx = DeviceArray.from_numpy(idx)  # resident before the timed region
     idx_stride = R * 3 * 4
 
@@ -603,6 +607,9 @@ def main():
                 "global_rays": R * world,
                 "samples_per_ray": S,
                 "parallelism": f"dp{world}",
+                "sharding": "rank r trains rays [r x rays_per_gpu, (r + 1) x rays_per_gpu) of one global rand() draw per "
+                            "step (nerf_draw_ray_indices_shard); one all-reduce(sum) of [gradients | squared error]; "
+                            "AdamW with the global point count on every rank",
                 "collective": collective,
                 "device": info["name"],
                 "compute_units": info["compute_units"],

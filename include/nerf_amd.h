@@ -128,6 +128,14 @@ void nerf_dataset_release(NerfDeviceDataset* d);
 /* the three rand() draws per ray of generate_random_batch (nerf.c:168-173), in that order:
  * idx[3*ray + {0,1,2}] = image, u, v */
 void nerf_draw_ray_indices(const Dataset* dataset, int rays_per_batch, int* idx);
+/* Data parallelism over rays (no counterpart in the reference, single-GPU train.c:48): rank `rank` of
+ * `world` takes the contiguous block [rank*global_rays/world, (rank+1)*global_rays/world) of ONE global
+ * batch.  Every rank calls this with rand() in the same state (same srand): all 3*global_rays draws of
+ * nerf.c:168-173 are made in the reference's order on every rank, and idx[3*per_rank] receives this
+ * rank's block only -- the blocks of all ranks, put end to end, are exactly what
+ * nerf_draw_ray_indices(dataset, global_rays, ...) returns from that state, and rand() is left in the
+ * same state.  Returns 1 when global_rays does not divide by world (or a bad argument). */
+int nerf_draw_ray_indices_shard(const Dataset* dataset, int global_rays, int rank, int world, int* idx);
 
 /* ---- encode: generate_ray + sampling + positional encoding on the device ---------------------- */
 /* stands in for generate_random_batch + batch_positional_encoding + the H2D copy
@@ -297,7 +305,10 @@ int nerf_dp_unique_id(unsigned char* id128);
  * have joined.  NULL on failure. */
 NerfDp* nerf_dp_init(int rank, int world, const unsigned char* id128);
 /* the same with the id handed over through a file all ranks can reach: rank 0 writes it, the others
- * wait up to timeout_seconds (<= 0: 120) for it to appear; rank 0 removes it afterwards */
+ * wait up to timeout_seconds (<= 0: 120) for it to appear; rank 0 removes it afterwards.  `path` must
+ * be unique to the run (e.g. from mkstemp; an empty file under that name is fine): a whole id left
+ * under a fixed name by a run that crashed would be taken for this run's.  NULL when the path is longer
+ * than 1000 bytes. */
 NerfDp* nerf_dp_init_from_file(int rank, int world, const char* path, int timeout_seconds);
 void nerf_dp_destroy(NerfDp* dp);
 int nerf_dp_rank(const NerfDp* dp);

@@ -122,6 +122,7 @@ _SIGS = {
     "nerf_dataset_upload_cameras": (VP, [C.POINTER(Dataset)]),
     "nerf_dataset_release": (None, [VP]),
     "nerf_draw_ray_indices": (None, [C.POINTER(Dataset), C.c_int, c_int_p]),
+    "nerf_draw_ray_indices_shard": (C.c_int, [C.POINTER(Dataset), C.c_int, C.c_int, C.c_int, c_int_p]),
     "nerf_encode_batch": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, VP,
                                     C.c_int, VP, VP]),
     "nerf_encode_batch_bf16": (C.c_int, [VP, VP, VP, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, VP,

@@ -129,6 +129,15 @@ class HostDataset:
         lib.nerf_draw_ray_indices(C.byref(self.struct), rays, idx.ctypes.data_as(_lib.c_int_p))
         return idx
 
+    def draw_ray_indices_shard(self, global_rays, rank, world):
+        """this rank's contiguous block of ONE global draw (every rank calls it under the same srand)"""
+        if world < 1 or global_rays % world != 0:
+            raise ValueError(f"{global_rays} rays do not split evenly over {world} ranks")
+        idx = np.empty((global_rays // world, 3), np.int32)
+        _check(lib.nerf_draw_ray_indices_shard(C.byref(self.struct), global_rays, rank, world,
+                                               idx.ctypes.data_as(_lib.c_int_p)), "nerf_draw_ray_indices_shard")
+        return idx
+
 
 class DeviceDataset:
     def __init__(self, handle):

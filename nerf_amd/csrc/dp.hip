@@ -116,13 +116,19 @@ NerfDp* nerf_dp_init(int rank, int world, const unsigned char* id) {
 // reader never sees half of it), the other ranks wait until the file holds a whole id (a caller may
 // have reserved the name with an empty file).  ncclCommInitRank returns
 // once every rank has joined, after which rank 0 removes the file.
+// `path` must be a name of THIS run's own (mkstemp, or a name carrying the launcher's process id): a
+// rank cannot tell a whole id left behind by a run that crashed from the one it is waiting for.
 NerfDp* nerf_dp_init_from_file(int rank, int world, const char* path, int timeout_seconds) {
     if (!path || world < 1 || rank < 0 || rank >= world) return nullptr;
     unsigned char id[NERF_DP_ID_BYTES];
     if (rank == 0) {
         if (nerf_dp_unique_id(id) != NERF_OK) return nullptr;
         char tmp[1024];
-        snprintf(tmp, sizeof(tmp), "%s.tmp", path);
+        if (snprintf(tmp, sizeof(tmp), "%s.tmp", path) >= (int)sizeof(tmp)) {
+            fprintf(stderr, "nerf_dp: the id file's path is too long\n");
+            return nullptr;
+        }
+        unlink(tmp);  // what an earlier run that died between creating and renaming it left behind
         // a new file of this process only: never through a link someone left under that name
         const int fd = open(tmp, O_CREAT | O_EXCL | O_WRONLY, 0600);
         FILE* f = fd >= 0 ? fdopen(fd, "wb") : nullptr;

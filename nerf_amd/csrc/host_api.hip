@@ -59,6 +59,28 @@ void nerf_draw_ray_indices(const Dataset* dataset, int rays_per_batch, int* idx)
     }
 }
 
+int nerf_draw_ray_indices_shard(const Dataset* dataset, int global_rays, int rank, int world, int* idx) {
+    if (!dataset || !idx || dataset->num_images <= 0 || world < 1 || rank < 0 || rank >= world || global_rays < 0 ||
+        global_rays % world != 0)
+        return NERF_ERR_ARG;
+    const int per = global_rays / world, first = rank * per;
+    // every ray of the global batch takes its three draws (nerf.c:168-173), so rand() ends in the state
+    // the single-process draw leaves it in; only this rank's block [first, first + per) is kept
+    for (int ray = 0; ray < global_rays; ray++) {
+        const int img = rand() % dataset->num_images;
+        const Camera* cam = dataset->cameras[img];
+        const int u = rand() % cam->width;
+        const int v = rand() % cam->height;
+        if (ray >= first && ray < first + per) {
+            int* dst = idx + 3 * (size_t)(ray - first);
+            dst[0] = img;
+            dst[1] = u;
+            dst[2] = v;
+        }
+    }
+    return NERF_OK;
+}
+
 void positional_encoding(const float* input, int input_dim, int L, float* output) {
     const size_t out_n = (size_t)input_dim + 2 * (size_t)input_dim * L;
     float *d_in = nullptr, *d_out = nullptr;

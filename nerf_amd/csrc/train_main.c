@@ -25,16 +25,31 @@
  * arrangement.  --fuse-pair needs the device-side step (--path fused, the default).
  *
  * --ranks N (device-side step only; the reference is single-GPU, train.c:48): data parallelism over
- * rays.  The driver forks into N processes before anything touches the GPU, rank r takes device r,
- * every rank draws and trains its own --rays rays per step, the weight gradients and the squared error
- * are summed with one RCCL all-reduce (nerf_dp_*), and every rank applies the same AdamW step with the
- * global point count as divisor.  Rank 0 logs (loss over the global batch), renders and saves.
+ * rays.  --rays is then the share of ONE rank: the global batch is N x --rays rays.  Every rank seeds
+ * rand() alike before a batch, makes all three-draws-per-ray of the GLOBAL batch in the reference's
+ * order (nerf.c:168-173) and keeps rays [r x --rays, (r+1) x --rays) (nerf_draw_ray_indices_shard), so
+ * `--ranks N --rays R --seed s` trains on exactly the rays of `--rays N*R --seed s`.  The weight
+ * gradients and the squared error are summed with one RCCL all-reduce (nerf_dp_*), and every rank
+ * applies the same AdamW step with the global point count as divisor.  Rank 0 logs (loss over the
+ * global batch), renders and saves.
+ *   Processes: this process stays free of the GPU and only supervises.  It forks all N ranks (rank r
+ * takes device r); when a rank ends with a failure, or the supervisor is told to stop, it ends the other
+ * ranks (SIGTERM, then SIGKILL), removes the communicator-id file and exits non-zero -- a rank that
+ * died can never leave the others blocked in a collective.  Ranks also end when the supervisor dies.
  * --ranks 1 runs the same code path on one GPU.
+ *
+ * --virtual-ranks N: the same sharding in ONE process on ONE GPU, without a communicator: the N shards
+ * of each global batch go through nerf_trainer_forward_backward / _add one after the other and one
+ * AdamW step with the global divisor follows.  What N ranks compute, up to the association of the
+ * gradient sums; for checking the sharding where only one GPU is at hand.
  */
+#include <errno.h>
 #include <math.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/prctl.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 #include <time.h>
@@ -44,11 +59,14 @@
 #include "nerf_kernels.h"
 #include "nerf_spec.h"
 
+#define MAX_RANKS 64
+
 typedef struct {
     const char* data_dir;
     int max_images, rays, samples, batches, fused, render_every, log_every;
     int split_math, fuse_pair, pin;
     int ranks; /* 0: no communicator at all (the default); N >= 1: N processes, one per GPU */
+    int virtual_ranks; /* N >= 1: the N shards of each global batch one after the other in this process */
     long seed; /* < 0: srand(time(NULL)) and rand() everywhere, like train.c:13.  >= 0: repeatable run (see main) */
     const char* save_prefix;
     const char* resume[2];
@@ -68,6 +86,7 @@ static int parse_options(int argc, char** argv, Options* o) {
     o->fuse_pair = 0;
     o->pin = 1;
     o->ranks = 0;
+    o->virtual_ranks = 0;
     o->save_prefix = NULL;
     o->resume[0] = o->resume[1] = NULL;
     int positional = 0;
@@ -92,6 +111,7 @@ static int parse_options(int argc, char** argv, Options* o) {
             } else if (!strcmp(a, "--fuse-pair")) o->fuse_pair = atoi(v) != 0;
             else if (!strcmp(a, "--pin")) o->pin = atoi(v) != 0;
             else if (!strcmp(a, "--ranks")) o->ranks = atoi(v);
+            else if (!strcmp(a, "--virtual-ranks")) o->virtual_ranks = atoi(v);
             else return -1;
             i++;
         } else if (positional < 2) {
@@ -101,7 +121,8 @@ static int parse_options(int argc, char** argv, Options* o) {
         }
     }
     if (positional == 1) return -1; /* train.c:127-131: none or both */
-    if (o->ranks < 0 || o->ranks > 64) return -1;
+    if (o->ranks < 0 || o->ranks > MAX_RANKS) return -1;
+    if (o->virtual_ranks < 0 || o->virtual_ranks > MAX_RANKS || (o->ranks > 0 && o->virtual_ranks > 0)) return -1;
     return 0;
 }
 
@@ -183,60 +204,24 @@ static double seconds_now(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-int main(int argc, char** argv) {
-    Options o;
-    if (parse_options(argc, argv, &o) != 0) {
-        fprintf(stderr, "Usage: %s [options] [model1.bin model2.bin]\n"
-                        "  no model files: start new training; two: continue from them\n"
-                        "  --data DIR --images N --rays R --samples S --batches B --path classic|fused\n"
-                        "  --render-every K --log-every K --seed X --save PREFIX --ranks N\n", argv[0]);
-        return -1;
-    }
+/* seed of rand() before the draws of one batch: the same on every rank, so that every rank draws the
+ * same global batch */
+static unsigned batch_seed(long base, int batch) { return (unsigned)(base + 7919L * (batch + 1)); }
 
+/* One rank's whole run (or the single process's when world == 1 and id_path == NULL).  `shards` > 1
+ * without a communicator = virtual ranks.  seed_base: what rand() is re-seeded from before each batch
+ * when ranks or virtual ranks are in play, or o->seed >= 0. */
+static int train_run(Options o, Dataset* ds, int rank, int world, const char* id_path, long seed_base) {
     const int pe_dim = NERF_PE_DIM3(NERF_DEFAULT_POS_ENC_L) + NERF_PE_DIM3(NERF_DEFAULT_DIR_ENC_L);
     const int hidden = NERF_DEFAULT_HIDDEN_DIM, inter = NERF_DEFAULT_INTERMEDIATE_DIM, out_dim = NERF_DEFAULT_OUTPUT_DIM;
     const int points = o.rays * o.samples;
-
-    char json_path[600];
-    snprintf(json_path, sizeof(json_path), "%s/transforms.json", o.data_dir);
-    Dataset* ds = load_dataset(json_path, o.data_dir, o.max_images);
-    if (!ds || ds->num_images == 0) {
-        fprintf(stderr, "Failed to load dataset\n");
+    const int shards = o.virtual_ranks > 0 ? o.virtual_ranks : world; /* blocks the global batch is cut into */
+    const int reseed = o.seed >= 0 || o.ranks > 0 || o.virtual_ranks > 0;
+    if ((long long)points * shards > 0x7fffffffLL || (long long)o.rays * shards > 0x7fffffffLL / 3) {
+        fprintf(stderr, "%d x %d rays x %d samples: the global batch is too large\n", shards, o.rays, o.samples);
         return -1;
     }
 
-    /* data parallelism: one process per GPU, forked while the process is still GPU-free (the dataset
-     * above is host memory and is shared copy-on-write) */
-    int rank = 0;
-    const int world = o.ranks > 0 ? o.ranks : 1;
-    pid_t kids[64];
-    char id_path[128] = "";
-    if (o.ranks > 0 && !o.fused) {
-        fprintf(stderr, "--ranks needs --path fused\n");
-        return -1;
-    }
-    if (o.ranks > 0) { /* a name of this run's own; the file stays empty until rank 0 publishes the id */
-        snprintf(id_path, sizeof(id_path), "/tmp/nerf_dp_XXXXXX");
-        const int fd = mkstemp(id_path);
-        if (fd < 0) {
-            perror("mkstemp");
-            return -1;
-        }
-        close(fd);
-    }
-    fflush(NULL);
-    for (int r = 1; r < world; r++) {
-        const pid_t p = fork();
-        if (p < 0) {
-            perror("fork");
-            return -1;
-        }
-        if (p == 0) {
-            rank = r;
-            break;
-        }
-        kids[r] = p;
-    }
     if (world > nerf_device_count()) {
         if (rank == 0) fprintf(stderr, "--ranks %d needs %d GPUs, %d visible\n", world, world, nerf_device_count());
         return -1;
@@ -247,7 +232,6 @@ int main(int argc, char** argv) {
         dp = nerf_dp_init_from_file(rank, world, id_path, 120);
         if (!dp) {
             fprintf(stderr, "rank %d: failed to join the communicator\n", rank);
-            if (rank == 0) unlink(id_path);
             return -1;
         }
     }
@@ -263,7 +247,7 @@ int main(int argc, char** argv) {
     /* train.c:13.  The HIP runtime draws from rand() itself (first allocations, first launches), so
      * one srand() cannot make a run repeatable.  With --seed the weights come from the library's
      * own generator and rand() is re-seeded right before every batch's three-draws-per-ray. */
-    srand((o.seed < 0 ? (unsigned)time(NULL) : (unsigned)o.seed) + 104729u * (unsigned)rank);
+    srand(o.seed < 0 ? (unsigned)time(NULL) : (unsigned)o.seed);
 
     /* MLPs: fresh, or resumed with the reference's dimension check */
     MLP *mlp1 = NULL, *mlp2 = NULL;
@@ -369,7 +353,11 @@ int main(int argc, char** argv) {
     }
 
     printf("Starting NeRF training with %d batches...\n", o.batches);
-    printf("Batch size: %d rays, %d samples per ray\n", o.rays, o.samples);
+    if (shards > 1)
+        printf("Batch size: %d rays in %d %s of %d, %d samples per ray\n", o.rays * shards, shards,
+               o.virtual_ranks > 0 ? "virtual ranks' shards" : "ranks' shards", o.rays, o.samples);
+    else
+        printf("Batch size: %d rays, %d samples per ray\n", o.rays, o.samples);
     printf("Network: %d -> %d -> %d -> %d -> %d\n", pe_dim, hidden, inter, hidden, out_dim);
     if (o.split_math || o.fuse_pair)
         printf("Options: %s products%s\n", o.split_math ? "split-bf16" : "exact fp32",
@@ -382,9 +370,23 @@ int main(int argc, char** argv) {
     const double t0 = seconds_now();
     for (int batch = first; batch < first + o.batches; batch++) {
         if (batch % NERF_LR_DECAY_EVERY == 0) lr *= NERF_LR_DECAY;
-        if (o.seed >= 0) srand((unsigned)(o.seed + 7919L * (batch + 1) + 104729L * rank));
-        if (o.fused) {
-            nerf_draw_ray_indices(ds, o.rays, idx);
+        if (reseed) srand(batch_seed(seed_base, batch));
+        if (o.fused && o.virtual_ranks > 0) {
+            /* what `shards` ranks do, one after the other: every shard is cut from the same global draw */
+            for (int v = 0; v < shards; v++) {
+                srand(batch_seed(seed_base, batch));
+                if (nerf_draw_ray_indices_shard(ds, o.rays * shards, v, shards, idx) != 0) return -1;
+                CHECK_HIP(nerf_memcpy_h2d(d_idx, idx, (size_t)o.rays * 3 * sizeof(int)));
+                if (v == 0) CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx, NULL));
+                else CHECK_HIP(nerf_trainer_forward_backward_add(trainer, dds, d_idx, NULL));
+            }
+            CHECK_HIP(nerf_trainer_update(trainer, lr, points * shards));
+        } else if (o.fused) {
+            if (dp) { /* this rank's block of the global batch */
+                if (nerf_draw_ray_indices_shard(ds, o.rays * world, rank, world, idx) != 0) return -1;
+            } else {
+                nerf_draw_ray_indices(ds, o.rays, idx);
+            }
             CHECK_HIP(nerf_memcpy_h2d(d_idx, idx, (size_t)o.rays * 3 * sizeof(int)));
             CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx, NULL));
             if (dp) CHECK_HIP(nerf_dp_allreduce_grads(dp, trainer)); /* gradients and squared error of all ranks */
@@ -395,14 +397,14 @@ int main(int argc, char** argv) {
         if (o.log_every > 0 && (batch + 1) % o.log_every == 0) {
             float loss;
             if (o.fused) {
-                loss = nerf_trainer_last_loss(trainer) / (float)world; /* the sum is global, the divisor per rank */
+                loss = nerf_trainer_last_loss(trainer) / (float)shards; /* the sum is global, the divisor per shard */
             } else {
                 CHECK_HIP(nerf_memcpy_d2h(&loss, cb.d_loss, sizeof(float)));
                 loss /= (float)o.rays;
             }
             const double el = seconds_now() - t0;
             printf("Batch [%d/%d], Loss: %.6f, LR: %.6f  (%.0f rays/s)\n", batch + 1, first + o.batches, loss, lr,
-                   (double)(batch + 1 - first) * o.rays * world / el);
+                   (double)(batch + 1 - first) * o.rays * shards / el);
             if (o.render_every > 0 && (batch + 1) % o.render_every == 0)
                 render_test_image(mlp1, mlp2, ds, batch + 1, NULL, o.samples, NERF_DEFAULT_NEAR, NERF_DEFAULT_FAR,
                                   NERF_DEFAULT_POS_ENC_L, NERF_DEFAULT_DIR_ENC_L, pe_dim, 128, 128);
@@ -410,22 +412,21 @@ int main(int argc, char** argv) {
     }
     CHECK_HIP(nerf_stream_synchronize());
 
-    int status = 0;
-    if (rank != 0) goto cleanup; /* one copy of the model is enough: all ranks hold the same weights */
-    char file1[300], file2[300];
-    if (o.save_prefix) {
-        snprintf(file1, sizeof(file1), "%s_nerf_model1.bin", o.save_prefix);
-        snprintf(file2, sizeof(file2), "%s_nerf_model2.bin", o.save_prefix);
-    } else {
-        time_t now = time(NULL);
-        strftime(file1, sizeof(file1), "%Y%m%d_%H%M%S_nerf_model1.bin", localtime(&now));
-        strftime(file2, sizeof(file2), "%Y%m%d_%H%M%S_nerf_model2.bin", localtime(&now));
+    if (rank == 0) { /* one copy of the model is enough: all ranks hold the same weights */
+        char file1[300], file2[300];
+        if (o.save_prefix) {
+            snprintf(file1, sizeof(file1), "%s_nerf_model1.bin", o.save_prefix);
+            snprintf(file2, sizeof(file2), "%s_nerf_model2.bin", o.save_prefix);
+        } else {
+            time_t now = time(NULL);
+            strftime(file1, sizeof(file1), "%Y%m%d_%H%M%S_nerf_model1.bin", localtime(&now));
+            strftime(file2, sizeof(file2), "%Y%m%d_%H%M%S_nerf_model2.bin", localtime(&now));
+        }
+        save_mlp(mlp1, file1);
+        save_mlp(mlp2, file2);
+        printf("\nTraining completed! Models saved to: %s and %s\n", file1, file2);
     }
-    save_mlp(mlp1, file1);
-    save_mlp(mlp2, file2);
-    printf("\nTraining completed! Models saved to: %s and %s\n", file1, file2);
 
-cleanup:
     if (dp) nerf_dp_destroy(dp);
     if (o.fused) {
         free(idx);
@@ -437,14 +438,141 @@ cleanup:
         free_mlp(mlp1);
         free_mlp(mlp2);
     }
-    free_dataset(ds);
-    if (rank == 0)
-        for (int r = 1; r < world; r++) {
-            int st = 0;
-            if (waitpid(kids[r], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
-                fprintf(stderr, "rank %d did not finish cleanly\n", r);
-                status = -1;
+    return 0;
+}
+
+/* ---- the supervisor of --ranks N: a process that never touches the GPU --------------------------- */
+static volatile sig_atomic_t g_stop_requested = 0;
+static void on_stop_signal(int sig) {
+    (void)sig;
+    g_stop_requested = 1;
+}
+
+/* ends every rank still running: SIGTERM, a grace period, then SIGKILL; reaps them all */
+static void end_ranks(pid_t* kids, int world) {
+    for (int r = 0; r < world; r++)
+        if (kids[r] > 0) kill(kids[r], SIGTERM);
+    for (int tenth = 0; tenth < 50; tenth++) {
+        int alive = 0;
+        for (int r = 0; r < world; r++)
+            if (kids[r] > 0) {
+                if (waitpid(kids[r], NULL, WNOHANG) == kids[r]) kids[r] = 0;
+                else alive++;
             }
+        if (!alive) return;
+        usleep(100000);
+    }
+    for (int r = 0; r < world; r++)
+        if (kids[r] > 0) {
+            kill(kids[r], SIGKILL);
+            waitpid(kids[r], NULL, 0);
+            kids[r] = 0;
         }
+}
+
+static int supervise(const Options* o, Dataset* ds) {
+    const int world = o->ranks;
+    const long seed_base = o->seed >= 0 ? o->seed : (long)time(NULL);
+    pid_t kids[MAX_RANKS];
+    memset(kids, 0, sizeof(kids));
+    /* a name of this run's own; the file stays empty until rank 0 publishes the communicator's id */
+    char id_path[64], id_tmp[80];
+    snprintf(id_path, sizeof(id_path), "/tmp/nerf_dp_XXXXXX");
+    const int fd = mkstemp(id_path);
+    if (fd < 0) {
+        perror("mkstemp");
+        return -1;
+    }
+    close(fd);
+    snprintf(id_tmp, sizeof(id_tmp), "%s.tmp", id_path);
+
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = on_stop_signal; /* no SA_RESTART: waitpid below returns with EINTR */
+    sigaction(SIGINT, &sa, NULL);
+    sigaction(SIGTERM, &sa, NULL);
+
+    /* test hook: that rank (every rank if negative) blocks before it touches the GPU, as a rank stuck
+     * in communicator set-up or a collective would */
+    const char* hang = getenv("NERF_TRAIN_TEST_HANG_RANK");
+    const pid_t supervisor = getpid();
+    int failed = 0;
+    fflush(NULL);
+    for (int r = 0; r < world; r++) {
+        const pid_t p = fork();
+        if (p < 0) {
+            perror("fork");
+            failed = 1;
+            break;
+        }
+        if (p == 0) {
+            signal(SIGINT, SIG_DFL);
+            signal(SIGTERM, SIG_DFL);
+            prctl(PR_SET_PDEATHSIG, SIGTERM); /* a rank never outlives the supervisor */
+            if (getppid() != supervisor) _exit(EXIT_FAILURE); /* it died between fork and prctl */
+            if (hang && (atoi(hang) == r || atoi(hang) < 0))
+                for (;;) pause();
+            const int rc = train_run(*o, ds, r, world, id_path, seed_base);
+            fflush(NULL);
+            exit(rc == 0 ? EXIT_SUCCESS : EXIT_FAILURE);
+        }
+        kids[r] = p;
+    }
+    int running = 0;
+    for (int r = 0; r < world; r++) running += kids[r] > 0;
+    while (running > 0 && !failed) {
+        int st = 0;
+        const pid_t p = waitpid(-1, &st, 0);
+        if (p < 0) {
+            if (errno == EINTR && !g_stop_requested) continue;
+            if (g_stop_requested) fprintf(stderr, "stop requested: ending all ranks\n");
+            failed = 1;
+            break;
+        }
+        for (int r = 0; r < world; r++)
+            if (kids[r] == p) {
+                kids[r] = 0;
+                running--;
+                if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+                    if (WIFSIGNALED(st)) fprintf(stderr, "rank %d was ended by signal %d: ending the other ranks\n", r, WTERMSIG(st));
+                    else fprintf(stderr, "rank %d failed (exit status %d): ending the other ranks\n", r, WEXITSTATUS(st));
+                    failed = 1;
+                }
+            }
+    }
+    end_ranks(kids, world); /* nothing left to end after a clean run */
+    unlink(id_path);
+    unlink(id_tmp);
+    return failed ? -1 : 0;
+}
+
+int main(int argc, char** argv) {
+    Options o;
+    if (parse_options(argc, argv, &o) != 0) {
+        fprintf(stderr, "Usage: %s [options] [model1.bin model2.bin]\n"
+                        "  no model files: start new training; two: continue from them\n"
+                        "  --data DIR --images N --rays R --samples S --batches B --path classic|fused\n"
+                        "  --render-every K --log-every K --seed X --save PREFIX --ranks N | --virtual-ranks N\n", argv[0]);
+        return -1;
+    }
+    if ((o.ranks > 0 || o.virtual_ranks > 0) && !o.fused) {
+        fprintf(stderr, "--ranks and --virtual-ranks need --path fused\n");
+        return -1;
+    }
+
+    char json_path[600];
+    snprintf(json_path, sizeof(json_path), "%s/transforms.json", o.data_dir);
+    Dataset* ds = load_dataset(json_path, o.data_dir, o.max_images);
+    if (!ds || ds->num_images == 0) {
+        fprintf(stderr, "Failed to load dataset\n");
+        return -1;
+    }
+
+    /* data parallelism: one process per GPU, forked while this process is still GPU-free (the dataset
+     * above is host memory and is shared copy-on-write) */
+    int status;
+    if (o.ranks > 0) status = supervise(&o, ds);
+    else status = train_run(o, ds, 0, 1, NULL, o.seed >= 0 ? o.seed : (long)time(NULL));
+    free_dataset(ds);
     return status;
 }

@@ -34,12 +34,16 @@ class RcclGroup:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         uid = (ctypes.c_ubyte * 128)()
-        if self.rank == 0 and lib.nerf_dp_unique_id(uid) != 0:
-            raise RuntimeError("nerf_dp_unique_id failed (is librccl.so.1 installed?)")
+        have_id = self.rank != 0 or lib.nerf_dp_unique_id(uid) == 0
         if self.world_size > 1:
-            box = [bytes(uid)]
+            # rank 0 hands over the id, or None when it has none: the other ranks must not wait for ever
+            box = [bytes(uid) if have_id else None]
             dist.broadcast_object_list(box, src=0, group=group)
-            uid = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+            have_id = box[0] is not None
+            if have_id:
+                uid = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        if not have_id:
+            raise RuntimeError("nerf_dp_unique_id failed on rank 0 (is librccl.so.1 installed?)")
         self.handle = lib.nerf_dp_init(self.rank, self.world_size, uid)
         if not self.handle:
             raise RuntimeError("nerf_dp_init failed")

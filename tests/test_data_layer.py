@@ -312,6 +312,42 @@ def test_draw_ray_indices_follow_rand_order(lib, tmp_path, libc):
     lib.free_dataset(ds)
 
 
+def test_shards_of_one_global_draw_concatenate_to_the_single_process_stream(lib, tmp_path, libc):
+    """data parallelism over rays: rank r keeps rays [r*R/G, (r+1)*R/G) of ONE global draw.  The blocks
+    of all ranks, end to end, are bit for bit what nerf_draw_ray_indices gives a single process from the
+    same rand() state, for several batches in a row (every rank leaves rand() where the single process
+    does), for every world size that divides the batch"""
+    build_scene_dir(tmp_path, 3, (11, 7))
+    ds = lib.load_dataset(str(tmp_path / "transforms.json").encode(), str(tmp_path).encode(), 3)
+    P = C.POINTER(C.c_int)
+    R, batches = 24, 3
+    libc.srand(77)
+    whole = np.empty((batches, R, 3), np.int32)
+    for b in range(batches):
+        lib.nerf_draw_ray_indices(ds, R, whole[b].ctypes.data_as(P))
+    after = libc.rand()
+    for world in (1, 2, 3, 4, 8):
+        blocks = []
+        for rank in range(world):
+            libc.srand(77)  # every rank seeds alike
+            mine = np.full((batches, R // world, 3), -1, np.int32)
+            for b in range(batches):
+                assert lib.nerf_draw_ray_indices_shard(ds, R, rank, world, mine[b].ctypes.data_as(P)) == 0
+            assert libc.rand() == after
+            blocks.append(mine)
+        assert np.array_equal(np.concatenate(blocks, axis=1), whole), world
+    # a batch that does not split evenly, a rank outside the world, an empty world: refused, nothing drawn
+    libc.srand(5)
+    first = libc.rand()
+    libc.srand(5)
+    scratch = np.empty((R, 3), np.int32)
+    assert lib.nerf_draw_ray_indices_shard(ds, R, 0, 5, scratch.ctypes.data_as(P)) == 1
+    assert lib.nerf_draw_ray_indices_shard(ds, R, 2, 2, scratch.ctypes.data_as(P)) == 1
+    assert lib.nerf_draw_ray_indices_shard(ds, R, 0, 0, scratch.ctypes.data_as(P)) == 1
+    assert libc.rand() == first
+    lib.free_dataset(ds)
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REF_DATA, "transforms.json")),
                     reason="reference checkout not present (GPU box)")
 def test_bundled_scene_of_the_reference_loads(lib):

@@ -103,6 +103,97 @@ def test_c_driver_ranks_mode(gpu, tmp_path):
     assert p.returncode != 0 and "--path fused" in p.stderr
 
 
+def _losses(out):
+    return [float(l.split("Loss:")[1].split(",")[0]) for l in out.splitlines() if "Loss:" in l]
+
+
+@pytest.mark.parametrize("virtual", [2, 4])
+def test_virtual_ranks_of_the_c_driver_train_the_global_batch(gpu, tmp_path, virtual):
+    """--virtual-ranks N --rays R/N --seed s: every shard is rank r's contiguous block of ONE global
+    rand() draw (nerf_draw_ray_indices_shard), the N shards go through forward_backward / _add and one
+    AdamW step with the global divisor follows -- what N ranks compute.  Must train the model that
+    --rays R --seed s trains in one process: losses to 1e-5, weights within 0.02 lr."""
+    from test_gpu_driver import read_checkpoint, write_scene
+    write_scene(str(tmp_path))
+    R, batches = 32, 5
+    common = ["--data", str(tmp_path), "--images", "4", "--samples", "32", "--batches", str(batches), "--seed", "11",
+              "--log-every", "1", "--render-every", "0"]
+    outs = {}
+    for tag, extra in (("whole", ["--rays", str(R)]), ("shards", ["--rays", str(R // virtual), "--virtual-ranks", str(virtual)])):
+        p = subprocess.run([TRAIN] + common + extra + ["--save", tag], cwd=str(tmp_path), capture_output=True, text=True,
+                           timeout=110)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        outs[tag] = _losses(p.stdout)
+        assert len(outs[tag]) == batches
+    assert f"Batch size: {R} rays in {virtual} virtual ranks' shards of {R // virtual}" in p.stdout
+    np.testing.assert_allclose(outs["shards"], outs["whole"], rtol=1e-5)
+    lr = 1e-4 * 0.99
+    for k in (1, 2):
+        a, b = read_checkpoint(tmp_path / f"whole_nerf_model{k}.bin"), read_checkpoint(tmp_path / f"shards_nerf_model{k}.bin")
+        assert a["t"] == b["t"] == batches
+        for name in ("W1", "W2"):
+            assert np.abs(a[name] - b[name]).max() <= 0.02 * lr, (k, name)
+
+
+def test_virtual_ranks_at_the_reference_widths_through_the_python_mirror(gpu, oracle_fast):
+    """the same property through the C ABI directly, at the reference's widths (150-512-512-512-4,
+    128 samples): 8 shards of 64 rays, cut from one global draw of 512 rays, against one 512-ray batch:
+    gradient arena (sums over the batch) within 2e-5 of its largest entry, squared error to 1e-6"""
+    from nerf_amd._lib import lib
+    from nerf_amd.api import DeviceArray, HostDataset, Trainer, make_camera, trainer_config
+    libc = C.CDLL("libc.so.6")
+    cams, images = make_scene(3, 32, 24)
+    host = HostDataset([make_camera(*c) for c in cams], images)
+    dds = host.upload()
+    R, S, world = 512, 128, 8
+    whole = Trainer(trainer_config(rays_per_batch=R, num_samples=S))
+    part = Trainer(trainer_config(rays_per_batch=R // world, num_samples=S))
+    _, flat = flat_params(oracle_fast, whole.pe_dim, 512, 512, 4)
+    whole.set_params(flat)
+    part.set_params(flat)
+    libc.srand(21)
+    idx = host.draw_ray_indices(R)
+    whole.forward_backward(dds, DeviceArray.from_numpy(idx))
+    g_whole, sse_whole = whole.get_grads()
+    keep = []
+    for r in range(world):
+        libc.srand(21)
+        mine = host.draw_ray_indices_shard(R, r, world)
+        assert np.array_equal(mine, idx[r * (R // world):(r + 1) * (R // world)])
+        d_mine = DeviceArray.from_numpy(mine)
+        keep.append(d_mine)
+        fn = lib.nerf_trainer_forward_backward if r == 0 else lib.nerf_trainer_forward_backward_add
+        assert fn(part.handle, dds.handle, d_mine.ptr, 0) == 0
+    g_part, sse_part = part.get_grads()
+    assert abs(sse_part - sse_whole) <= 1e-6 * abs(sse_whole)
+    assert np.abs(g_part - g_whole).max() <= 2e-5 * np.abs(g_whole).max()
+    whole.update(1e-4, grad_points=R * S)
+    part.update(1e-4, grad_points=R * S)   # the GLOBAL divisor
+    assert np.abs(whole.get_params() - part.get_params()).max() <= 0.02 * 1e-4
+
+
+def test_two_ranks_of_the_c_driver_train_the_global_batch(gpu, tmp_path):
+    """--ranks 2 (two processes, two GPUs, RCCL) against --rays 2R in one process: needs two GPUs"""
+    from nerf_amd._lib import lib
+    if lib.nerf_device_count() < 2:
+        pytest.skip("fewer than 2 GPUs visible")
+    from test_gpu_driver import read_checkpoint, write_scene
+    write_scene(str(tmp_path))
+    common = ["--data", str(tmp_path), "--images", "4", "--samples", "32", "--batches", "5", "--seed", "11",
+              "--log-every", "1", "--render-every", "0"]
+    outs = {}
+    for tag, extra in (("whole", ["--rays", "32"]), ("two", ["--rays", "16", "--ranks", "2"])):
+        p = subprocess.run([TRAIN] + common + extra + ["--save", tag], cwd=str(tmp_path), capture_output=True, text=True,
+                           timeout=170)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        outs[tag] = _losses(p.stdout)
+    np.testing.assert_allclose(outs["two"], outs["whole"], rtol=1e-5)
+    for k in (1, 2):
+        a, b = read_checkpoint(tmp_path / f"whole_nerf_model{k}.bin"), read_checkpoint(tmp_path / f"two_nerf_model{k}.bin")
+        for name in ("W1", "W2"):
+            assert np.abs(a[name] - b[name]).max() <= 0.02 * 1e-4
+
+
 def test_hip_trainer_through_data_parallel_step(gpu, tmp_path):
     """Two ranks, each a HIP trainer on its contiguous half of every batch, stepped through
     DataParallelStep (shard bounds, broadcast of the start weights, ONE all-reduce over
@@ -165,3 +256,26 @@ def test_rccl_group_behind_data_parallel_step(gpu):
     assert torch.equal(flat.cpu(), torch.arange(1000, dtype=torch.float32))
     group.destroy()
     lib.nerf_set_stream(None)
+
+
+def test_bench_ranks_shard_one_global_draw(gpu):
+    """bench.py --gpus 2 (both ranks on the box's one GPU, gloo for the collective: RCCL refuses two
+    ranks on one device) against bench.py --gpus 1 with twice the rays: the two ranks keep contiguous
+    halves of the same global draw, so the loss after the last step must be the one-rank loss"""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--samples", "32", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"]
+    bench = os.path.join(ROOT, "bench.py")
+    one = subprocess.run([sys.executable, bench, "--gpus", "1", "--rays", "64"] + common, capture_output=True, text=True,
+                         timeout=170)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), bench, "--gpus", "2", "--rays", "32",
+                          "--rehearse-on-one-gpu"] + common, capture_output=True, text=True, timeout=170)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["config"]["global_rays"] == a["config"]["global_rays"] == 64
+    assert abs(a["final_loss_per_ray"] - b["final_loss_per_ray"]) <= 1e-5 * abs(a["final_loss_per_ray"])
