@@ -223,7 +223,7 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
     }
 
     if (world > nerf_device_count()) {
-        if (rank == 0) fprintf(stderr, "--ranks %d needs %d GPUs, %d visible\n", world, world, nerf_device_count());
+        fprintf(stderr, "rank %d: --ranks %d needs %d GPUs, %d visible\n", rank, world, world, nerf_device_count());
         return -1;
     }
     CHECK_HIP(nerf_set_device(rank));
