@@ -54,7 +54,11 @@ def test_convert_rounds_to_nearest_even_and_transposes(gpu):
 # the ring's four slots (K = 192: 6 slices, K = 320: 10), so consecutive tiles start in different slots.
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 512, 192), (4096, 512, 512), (130, 1024, 1024), (77, 24, 128),
                                    (16500, 1024, 128), (32768, 512, 192), (33000, 520, 64), (70000, 512, 192),
-                                   (66000, 1032, 320)])
+                                   (66000, 1032, 320),
+                                   # K = 512 and 1024 (the configuration's own contraction lengths) at the large shape:
+                                   # several tiles per workgroup, ragged in M and N; a grid of 258 tiles (two
+                                   # workgroups get a second tile); one tile per workgroup
+                                   (70000, 520, 512), (40000, 1032, 1024), (33000, 512, 512), (32768, 512, 1024)])
 @pytest.mark.parametrize("epilogue", [0, 1, 2])
 def test_nt_product(gpu, M, N, K, epilogue):
     from nerf_amd._lib import lib
