@@ -87,7 +87,7 @@ def pmc_traffic(kernel, mode=""):
 
 
 def cpu_baseline(seconds=12.0, rays=64, samples=128):
-    """The oracle's fast build (gcc -O3 -fopenmp, blocked products) running the same step."""
+    """The oracle's fast build (gcc -O3 -fopenmp, blocked products) running the same step on `rays` rays."""
     import numpy as np
     from oracle.pyoracle import ACC_FAST, Oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -190,9 +190,81 @@ def optin_train_rate(lib, host, dds, R, S, steps, warmup, split, fused):
     return out
 
 
+def reference_config_rate(lib, host, dds, R, S, steps, warmup, with_cpu):
+    """The reference's own configuration (train.c:16-17: 16 rays x 128 samples per step; also 64 and 256 rays,
+    the batch sizes at which the reference's arithmetic trains stably) through the device-side step, fp32,
+    timed like the headline: ray indices of every step drawn beforehand and resident, one synchronisation
+    on either side of `steps` steps.  A second pass with an event pair around every launch gives the
+    per-kernel figures; the matrix products are priced against the time the fp32 matrix cores need for
+    their FLOPs (each product is one 64x64 tile per CU at 16 rays, so a launch cannot take less)."""
+    import numpy as np
+    import torch
+    import nerf_amd
+    from nerf_amd.api import DeviceArray, Trainer, prof_read, trainer_config
+    tr = Trainer(trainer_config(rays_per_batch=R, num_samples=S))
+    tr.init_weights(seed=1, use_rand=False)
+    ctypes.CDLL("libc.so.6").srand(1000)
+    idx = np.concatenate([host.draw_ray_indices(R) for _ in range(warmup + steps)], axis=0)
+    d_idx = DeviceArray.from_numpy(idx)
+    stride = R * 3 * 4
+
+    def run(first, count):
+        for s in range(first, first + count):
+            nerf_amd.api._check(lib.nerf_trainer_step(tr.handle, dds.handle, d_idx.ptr + s * stride, 0), "step")
+        torch.cuda.synchronize()
+
+    run(0, warmup)
+    t0 = time.perf_counter()
+    run(warmup, steps)
+    elapsed = time.perf_counter() - t0
+    ev_steps = min(steps, 200)
+    lib.nerf_prof_reset()
+    lib.nerf_prof_enable(1)
+    run(warmup, ev_steps)
+    lib.nerf_prof_enable(0)
+    kernels, gemm_us, gemm_flop, gemm_launches = {}, 0.0, 0.0, 0
+    for name, (ms, launches, work) in prof_read().items():
+        if launches == 0:
+            continue
+        kernels[name] = {"us_per_step": ms / ev_steps * 1e3, "launches_per_step": launches / ev_steps}
+        if name.startswith("gemm"):
+            kernels[name]["tflops"] = work / (ms * 1e-3) / 1e12
+            gemm_us += ms / ev_steps * 1e3
+            gemm_flop += work / ev_steps
+            gemm_launches += launches / ev_steps
+    N = R * S
+    out = {
+        "metric": "trained rays/s @128 samples/ray",
+        "value": R * steps / elapsed,
+        "unit": "rays/s",
+        "us_per_step": elapsed / steps * 1e6,
+        "steps": steps,
+        "warmup": warmup,
+        "dtype": "f32",
+        "config": {"workload": f"full training step, {R} rays x {S} samples per step (train.c:16-17 at 16 rays), MLP "
+                               "150-512-512-512-4, fp32, ray indices resident"},
+        "final_loss_per_ray": tr.last_loss(),
+        "kernels_us_per_step_sum": sum(k["us_per_step"] for k in kernels.values()),
+        "kernels": kernels,
+        "matrix_products": {
+            "us_per_step": gemm_us,
+            "launches_per_step": gemm_launches,
+            "us_at_fp32_mfma_peak": gemm_flop / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6,
+            "frac_of_peak": gemm_flop / (PEAK_F32_MFMA_TFLOPS * 1e12) * 1e6 / gemm_us if gemm_us else None,
+            "note": f"3 465 216 FLOP per point x {N} points; a launch also pays its own start-up and drains alone "
+                    "(kernels of one step run one after the other)",
+        },
+    }
+    tr.destroy()
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(seconds=4.0, rays=R, samples=S)
+    return out
+
+
 def render_workload(args, lib, torch):
     """nerf_render_view on one 800x800 view (640 000 rays x 128 samples, 98.8 TFLOP of products): the
-    whole call, including its buffer allocation and the D2H copy of the image."""
+    whole call, including the D2H copy of the image (the renderer keeps its device buffers between
+    calls; the warm-up calls allocate them)."""
     import numpy as np
 
     import nerf_amd
@@ -625,6 +697,10 @@ def main():
             tr.destroy()
             del params, grads, d_idx
             out["secondary"] = {}
+            # the reference's own batch size (train.c:16-17) and the two larger ones its arithmetic still trains at
+            for rays_ref in (16, 64, 256):
+                out["secondary"][f"reference_config_{rays_ref}x{S}"] = reference_config_rate(
+                    lib, host, dds, rays_ref, S, 2000 if rays_ref <= 64 else 600, 200, with_cpu=(rays_ref == 16))
             for key, sp, fu in (("train_split_bf16_products", True, False), ("train_linear_pair_fused", False, True),
                                 ("train_split_bf16_products_linear_pair_fused", True, True)):
                 out["secondary"][key] = optin_train_rate(lib, host, dds, R, S, 20, 5, sp, fu)

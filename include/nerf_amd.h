@@ -341,6 +341,8 @@ int nerf_render_view(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int 
 enum { NERF_RENDER_FUSE_LINEAR_PAIR = 1, NERF_RENDER_SPACING_QUADRATURE = 2 };
 /* Both render functions keep their device buffers (one chunk's activations, the picture) between calls
  * and rebuild them when the chunk size, the sample count or an MLP width changes; this frees them.
+ * The buffers are shared by the whole process: a lock lets one render (or release) run at a time, so
+ * calls from several host threads are safe but do not overlap.
  * The reference allocates and frees its render MLPs per picture (nerf.c:232-233,338-339). */
 void nerf_render_release(void);
 int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,

@@ -49,28 +49,34 @@ __device__ __forceinline__ float expf_fast(float x) {
 }
 
 // 1 / (1 + expf(-x)) (nerf.c:15-17).  The division is a reciprocal and one Newton step (within an ulp
-// of the IEEE quotient; the denominator is >= 1) instead of the ten-instruction IEEE sequence; the
-// exponent is capped at 88 so that the denominator stays finite (sigmoid(-88) = 6e-39 either way).
-// Absolute error below 1e-7.
+// of the IEEE quotient; the denominator is >= 1) instead of the ten-instruction IEEE sequence.  The
+// exponent is kept inside [-104, 88]: above 88 the denominator would overflow (sigmoid(-88) = 6e-39
+// either way); below -104 expf is zero in fp32 anyway, and expf_fast's integer part would leave the
+// range of an int for huge positive x (+inf, 1e30: the reference returns 1.0 there, nerf.c:15-17, and
+// so does this).  Absolute error below 1e-7.
 __device__ __forceinline__ float sigmoid_ref(float x) {
-    const float d = 1.0f + expf_fast(fminf(-x, 88.0f));
+    const float d = 1.0f + expf_fast(fmaxf(fminf(-x, 88.0f), -104.0f));
     const float r = __builtin_amdgcn_rcpf(d);
     return fmaf(fmaf(-d, r, 1.0f), r, r);
 }
 
 // expf rounded correctly, for x <= 0: alpha = 1 - expf(-0.01 * density) cancels for small densities,
 // so a one-ulp difference in expf moves alpha by 6e-8 whatever its size -- up to 1e-3 RELATIVE on the
-// weights of a thin medium.  The correctly rounded value is what a host libm returns.  Evaluated in
-// double precision: x = k ln2 + r with |r| <= ln2/2, a degree-10 Taylor polynomial of exp(r)
-// (truncation 2e-13 relative, so the float rounding differs from the exact one about once in 10^5
-// arguments), scaled by 2^k and rounded to float once.  18 double-precision instructions, half of
-// what the general-purpose exp() spends on ranges that cannot occur here.
+// weights of a thin medium.  The correctly rounded value is what a host libm returns (glibc's expf
+// stays within 0.502 ulp, i.e. it is the correctly rounded value except about once in 10^3 arguments
+// that lie next to a rounding boundary).  Evaluated in double precision: x = k ln2 + r with
+// |r| <= ln2/2, a degree-12 Taylor polynomial of exp(r) (truncation r^13/13! < 2e-16 relative, the
+// size of one double rounding: the float rounding differs from the exact one for about one argument
+// in 10^8), scaled by 2^k and rounded to float once.  20 double-precision instructions, half of what
+// the general-purpose exp() spends on ranges that cannot occur here.
 __device__ __forceinline__ float expf_cr(float xf) {
     const double x = (double)fmaxf(xf, -104.0f);  // exp(-104) < 2^-150 rounds to zero: so does everything below (and -inf)
     const double kd = __builtin_rint(x * 1.4426950408889634074);
     double r = __builtin_fma(kd, -6.93147180369123816490e-01, x);  // ln2 split so that kd * hi is exact
     r = __builtin_fma(kd, -1.90821492927058770002e-10, r);
-    double p = 2.7557319223985890653e-07;          // 1/10!
+    double p = 2.0876756987868098979e-09;          // 1/12!
+    p = __builtin_fma(p, r, 2.5052108385441718775e-08);  // 1/11!
+    p = __builtin_fma(p, r, 2.7557319223985890653e-07);  // 1/10!
     p = __builtin_fma(p, r, 2.7557319223985892511e-06);  // 1/9!
     p = __builtin_fma(p, r, 2.4801587301587301566e-05);  // 1/8!
     p = __builtin_fma(p, r, 1.9841269841269841253e-04);  // 1/7!

@@ -15,6 +15,7 @@
 // Weights, gradients and both AdamW moments of the two MLPs live in four flat arenas with the
 // layout [mlp1.W1 | mlp1.W2 | mlp2.W1 | mlp2.W2]; the gradient arena has one extra slot for the
 // summed squared error so that a data-parallel caller all-reduces a single buffer.
+#include <mutex>
 #include "mlp_internal.hpp"
 #include "trainer_bf16.hpp"
 #include "../../include/nerf_amd.h"
@@ -585,6 +586,9 @@ struct RenderCache {
     unsigned char* d_rgb8;
 };
 RenderCache g_render = {};
+// One render at a time: the cache is shared by every caller of the process.  Held from the moment the
+// cache is fitted to a call until that call's picture has reached the host, and by nerf_render_release.
+std::mutex g_render_mutex;
 
 void render_cache_free() {
     if (g_render.r1) free_mlp(g_render.r1);
@@ -638,7 +642,10 @@ int render_cache_prepare(const MLP* mlp1, const MLP* mlp2, int N, int pe_ld, siz
 }
 }  // namespace
 
-void nerf_render_release(void) { render_cache_free(); }
+void nerf_render_release(void) {
+    std::lock_guard<std::mutex> lock(g_render_mutex);
+    render_cache_free();
+}
 
 int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w, int render_h, int num_samples,
                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, int rays_per_chunk,
@@ -658,6 +665,7 @@ int nerf_render_view_opts(MLP* mlp1, MLP* mlp2, const Camera* cam, int render_w,
     if ((long long)rays_per_chunk * num_samples > 0x7fffffffLL) return NERF_ERR_ARG;  // as nerf_trainer_create
     const int N = rays_per_chunk * num_samples;
     const int pe_ld = ((pe_dim + 31) / 32) * 32;  // pitched like the trainer's encoding (zero row tails)
+    std::lock_guard<std::mutex> lock(g_render_mutex);
     int rc = render_cache_prepare(mlp1, mlp2, N, pe_ld, (size_t)total);
     if (rc != NERF_OK) return rc;
     MLP *r1 = g_render.r1, *r2 = g_render.r2;

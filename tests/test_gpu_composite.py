@@ -61,6 +61,37 @@ def test_launchers_match_oracle(gpu, oracle, R, S):
     assert np.array_equal(g[:, 0] == 0, o_g[:, 0] == 0) or np.abs(g[:, 0] - o_g[:, 0]).max() < 1e-6 * scale
 
 
+def test_activation_of_extreme_raw_outputs(gpu, oracle):
+    """1 / (1 + expf(-x)) (nerf.c:15-17) at +-inf, +-1e30 and around the fp32 range of expf: the
+    reference's formula gives exactly 1 and 0 there, never NaN; so must the device, on the stand-alone
+    activation and on the activation fused into the compositing kernels"""
+    from nerf_amd.api import DeviceArray
+    from nerf_amd._lib import lib
+    xs = np.array([np.inf, -np.inf, 1e30, -1e30, 3e9, -3e9, 104.5, -104.5, 88.5, -88.5, 87.0, -87.0, 0.0, -0.0],
+                  np.float32)
+    S = xs.size
+    y = np.zeros((S, 4), np.float32)
+    y[:, 0] = np.array([np.inf, -np.inf, 1e30, -1e30] + [1.0] * (S - 4), np.float32)  # ReLU of the same extremes
+    y[:, 1], y[:, 2], y[:, 3] = xs, xs[::-1], xs
+    d_y, d_dens, d_rgb = DeviceArray.from_numpy(y), DeviceArray((S,)), DeviceArray((S, 3))
+    lib.activation_kernel_launch(d_y.ptr, d_dens.ptr, d_rgb.ptr, S, 4)
+    dens, rgb = d_dens.numpy(), d_rgb.numpy()
+    o_dens, o_rgb = oracle.activation(y)
+    assert np.isfinite(rgb).all() and np.isfinite(o_rgb).all()
+    assert np.array_equal(dens, o_dens)
+    np.testing.assert_allclose(rgb, o_rgb, rtol=0, atol=2e-7)
+    assert rgb[0, 0] == 1.0 and rgb[1, 0] == 0.0 and rgb[2, 0] == 1.0 and rgb[3, 0] == 0.0
+    # the fused path: one ray of S samples with finite densities, same colours
+    y[:, 0] = 1.0
+    d_pix = DeviceArray((1, 3))
+    assert lib.nerf_composite_forward(DeviceArray.from_numpy(y).ptr, 4, 0, 0, 0, 0, d_pix.ptr, 0, 1, S) == 0
+    o_dens, o_rgb = oracle.activation(y)
+    o_pix, _, _, _ = oracle.composite_and_loss(o_dens, o_rgb, np.zeros((S, 3), np.float32), 1, S)
+    pix = d_pix.numpy()
+    assert np.isfinite(pix).all()
+    np.testing.assert_allclose(pix, o_pix, rtol=0, atol=PIX_ATOL)
+
+
 def test_early_stop_is_reproduced(gpu, oracle):
     """An opaque ray stops contributing after transmittance falls below 0.01 in the forward pass
     (nerf.c:43) but the gradient kernel keeps weighting every sample (nerf.c:82-87)."""
