@@ -97,6 +97,24 @@ bool gemm_split_supported(const GemmArgs& args);
 
 // dst[i] = (accumulate ? dst[i] : 0) + sum_{s<splits} slabs[s*stride + i]   (fixed order: reproducible)
 void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate);
+// Several such sums as ONE launch: the weight gradients of a step are not read before the optimizer
+// runs, so their slab sums can wait for each other (at small batches a launch costs more than the sum
+// it carries).  Each job is summed exactly as reduce_slabs sums it: the same bits.  The slabs of a
+// queued job must stay untouched until flush().
+struct ReduceJob {
+    const float* slabs;
+    float* dst;
+    size_t stride, n;
+    int splits, accumulate;
+};
+struct ReduceQueue {
+    static constexpr int MAX_JOBS = 4;
+    ReduceJob jobs[MAX_JOBS];
+    int count = 0;
+    double bytes = 0.0;
+    void add(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate);  // flushes first when full
+    void flush();
+};
 
 // Picks the split count for a weight-gradient product with `tiles` output tiles over `rows` points.
 int choose_splits(int tiles, long rows, int* k_chunk);
@@ -134,11 +152,16 @@ void skinny_forward(const float* Hact, const float* W2, float* Y, long rows, int
 // EH[n][h] = (sum_o E[n][o] W2[o][h]) * swish'(Hpre[n][h]);  dW2[o][h] (+)= sum_n E[n][o] * swish(Hpre[n][h])
 // workspace: at least skinny_backward_workspace(rows, hidden, out_dim) bytes
 size_t skinny_backward_workspace(long rows, int hidden, int out_dim);
+// queue: where the sum of the workgroups' slabs into dW2 waits (nullptr: summed at once)
 void skinny_backward(const float* E, const float* Hpre, const float* W2, float* EH, float* dW2, long rows,
-                     int hidden, int out_dim, float* workspace, int accumulate, bool eh_split = false);
+                     int hidden, int out_dim, float* workspace, int accumulate, bool eh_split = false,
+                     ReduceQueue* queue = nullptr);
 
 // dst[i] = split word of src[i] (in place allowed)
 void to_split_words(const float* src, float* dst, size_t n);
+
+// ---- loss (composite.hip) ------------------------------------------------------------------------
+int loss_sum(const float* d_err, int R, float* d_loss, int accumulate);
 
 // ---- AdamW -------------------------------------------------------------------------------------
 void adamw_update(float* w, const float* g, float* m, float* v, size_t n, float grad_div, float beta1,

@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256) void composite_forward_kernel(
 
 // loss[0] += sum of squares of err[0..n): one workgroup, fixed summation order (reproducible;
 // the reference's atomicAdd at nerf.c:59 is order-dependent).
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ err, int n, float* loss) {
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ err, int n, float* loss,
+                                                           int accumulate = 1) {
     __shared__ float part[1024];
     float s = 0.0f;
     for (int i = threadIdx.x; i < n; i += 1024) s += err[i] * err[i];
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] += part[0];
+    if (threadIdx.x == 0) loss[0] = accumulate ? loss[0] + part[0] : part[0];
 }
 
 template <int SPL, bool RAW, bool SPACING>
@@ -475,6 +476,13 @@ int launch_backward(const float* raw, int out_dim, const float* dens_in, const f
 }
 
 }  // namespace
+
+// loss[0] = (accumulate ? loss[0] : 0) + sum of squares of err[R][3] (nerf.c:52-59), fixed summation order
+int loss_sum(const float* d_err, int R, float* d_loss, int accumulate) {
+    if (R <= 0 || !d_err || !d_loss) return NERF_ERR_ARG;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream(), d_err, R * 3, d_loss, accumulate);
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
 }  // namespace nerf
 
 using namespace nerf;
@@ -501,7 +509,7 @@ void volume_rendering_and_loss_launch(const float* d_densities, const float* d_c
         exit(EXIT_FAILURE);
     }
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream(), d_pixel_errors, rays_per_batch * 3,
-                       d_loss_accum);
+                       d_loss_accum, 1);
     NERF_HIP_CHECK(hipGetLastError());
 }
 
@@ -558,11 +566,7 @@ int nerf_stratified_offsets(float* d_offsets, long count, unsigned long long see
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
-int nerf_loss_accumulate(const float* d_err, int R, float* d_loss) {
-    if (R <= 0 || !d_err || !d_loss) return NERF_ERR_ARG;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream(), d_err, R * 3, d_loss);
-    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
-}
+int nerf_loss_accumulate(const float* d_err, int R, float* d_loss) { return nerf::loss_sum(d_err, R, d_loss, 1); }
 
 int nerf_composite_backward(const float* d_raw, int out_dim, const float* d_err, float* d_error_output, int R, int S) {
     if (R <= 0 || S <= 0 || out_dim != 4 || !d_raw || !d_err || !d_error_output) return NERF_ERR_ARG;

@@ -358,6 +358,41 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 
 inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
 
+// up to four slab sums in one launch: workgroup b works on the job whose block range holds b, with
+// the arithmetic of reduce_slabs_kernel (same order, same bits)
+struct ReduceBatch {
+    ReduceJob job[ReduceQueue::MAX_JOBS];
+    unsigned first_block[ReduceQueue::MAX_JOBS + 1];
+    int vec4[ReduceQueue::MAX_JOBS];
+    int count;
+};
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceBatch b) {
+    int j = 0;
+    while (j + 1 < b.count && blockIdx.x >= b.first_block[j + 1]) j++;
+    const ReduceJob& q = b.job[j];
+    const size_t t = (size_t)(blockIdx.x - b.first_block[j]) * 256 + threadIdx.x;
+    if (b.vec4[j]) {
+        const size_t i = t * 4;
+        if (i >= q.n) return;
+        f32x4 s = q.accumulate ? *reinterpret_cast<const f32x4*>(q.dst + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= q.splits; k += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x4*>(q.slabs + (size_t)(k + u) * q.stride + i);
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; k < q.splits; k++) s += *reinterpret_cast<const f32x4*>(q.slabs + (size_t)k * q.stride + i);
+        *reinterpret_cast<f32x4*>(q.dst + i) = s;
+    } else {
+        if (t >= q.n) return;
+        float s = q.accumulate ? q.dst[t] : 0.f;
+        for (int k = 0; k < q.splits; k++) s += q.slabs[(size_t)k * q.stride + t];
+        q.dst[t] = s;
+    }
+}
+
 // widest vector width (4, 2, 1) the operand allows
 int operand_vec(const float* ptr, int ld, int fast_extent) {
     if (aligned_to(ptr, 16) && ld % 4 == 0 && fast_extent % 4 == 0) return 4;
@@ -477,6 +512,35 @@ void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, siz
     else
         hipLaunchKernelGGL(reduce_slabs_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(),
                            slabs, splits, stride, dst, n, accumulate);
+}
+
+void ReduceQueue::add(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {
+    if (count == MAX_JOBS) flush();
+    jobs[count++] = ReduceJob{slabs, dst, stride, n, splits, accumulate};
+    bytes += (double)n * splits * 4.0;
+}
+
+void ReduceQueue::flush() {
+    if (count == 0) return;
+    ProfScope prof(K_REDUCE, bytes);
+    if (count == 1) {
+        reduce_slabs(jobs[0].slabs, jobs[0].splits, jobs[0].stride, jobs[0].dst, jobs[0].n, jobs[0].accumulate);
+    } else {
+        ReduceBatch b = {};
+        b.count = count;
+        unsigned blocks = 0;
+        for (int j = 0; j < count; j++) {
+            const ReduceJob& q = jobs[j];
+            b.job[j] = q;
+            b.vec4[j] = q.n % 4 == 0 && q.stride % 4 == 0 && aligned_to(q.slabs, 16) && aligned_to(q.dst, 16);
+            b.first_block[j] = blocks;
+            blocks += (unsigned)(((b.vec4[j] ? q.n / 4 : q.n) + 255) / 256);
+        }
+        for (int j = count; j <= MAX_JOBS; j++) b.first_block[j] = blocks;
+        hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, stream(), b);
+    }
+    count = 0;
+    bytes = 0.0;
 }
 
 }  // namespace nerf

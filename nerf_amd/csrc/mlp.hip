@@ -227,7 +227,7 @@ void to_split_words(const float* src, float* dst, size_t n) {
 }
 
 void skinny_backward(const float* E, const float* Hpre, const float* W2, float* EH, float* dW2, long rows,
-                     int hidden, int out_dim, float* workspace, int accumulate, bool eh_split) {
+                     int hidden, int out_dim, float* workspace, int accumulate, bool eh_split, ReduceQueue* queue) {
     const int blocks = skinny_backward_blocks(rows, hidden);
     const int rpi = 256 / (hidden / 4);
     long rpb = (rows + blocks - 1) / blocks;
@@ -250,6 +250,10 @@ void skinny_backward(const float* E, const float* Hpre, const float* W2, float* 
 #undef SKB
     }
     const size_t n = (size_t)out_dim * hidden;
+    if (queue) {
+        queue->add(workspace, blocks, n, dW2, n, accumulate);
+        return;
+    }
     ProfScope prof(K_REDUCE, (double)n * blocks * 4.0);
     reduce_slabs(workspace, blocks, n, dW2, n, accumulate);
 }
@@ -296,12 +300,16 @@ size_t wgrad_slab_bytes(int rows_out, int cols, long batch) {
     return (size_t)(a > b ? a : b) * rows_out * cols * sizeof(float);
 }
 
-size_t mlp_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int batch_size) {
-    const size_t need = wgrad_slab_bytes(hidden_dim, input_dim, batch_size);
+// The workspace of an MLP: the slabs of the output layer's weight gradient first, those of the hidden
+// layer's behind them (each on a 256-byte boundary): the two sums may wait in a ReduceQueue together.
+static size_t output_layer_slab_bytes(int hidden_dim, int output_dim, int batch_size) {
     const size_t need2 = skinny_ok(hidden_dim, output_dim)
                              ? skinny_backward_workspace(batch_size, hidden_dim, output_dim)
                              : wgrad_slab_bytes(output_dim, hidden_dim, batch_size);
-    return need > need2 ? need : need2;
+    return (need2 + 255) / 256 * 256;
+}
+size_t mlp_workspace_bytes(int input_dim, int hidden_dim, int output_dim, int batch_size) {
+    return output_layer_slab_bytes(hidden_dim, output_dim, batch_size) + wgrad_slab_bytes(hidden_dim, input_dim, batch_size);
 }
 
 // the product under the arithmetic `math` asks for; shapes the split-bf16 kernels do not take
@@ -321,7 +329,7 @@ bool split_words_ok(int H, long N) { return H > 160 && H % 32 == 0 && N > 128 &&
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T * Act[batch][cols]
 // Act rows are ld_act floats apart (ld_act >= cols; the trainer pads the 150-wide encoding to 160).
 void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, int ld_act, long batch, float* dW,
-                     float* workspace, int accumulate, int math, bool operands_split) {
+                     float* workspace, int accumulate, int math, bool operands_split, ReduceQueue* queue) {
     GemmArgs g = {};
     g.operands_split = operands_split;
     g.A = Err; g.lda = rows_out; g.a_kc = 0;
@@ -346,6 +354,10 @@ void weight_gradient(const float* Err, int rows_out, const float* Act, int cols,
         }
     }
     const size_t n = (size_t)rows_out * cols;
+    if (queue) {
+        queue->add(workspace, splits, n, dW, n, accumulate);
+        return;
+    }
     ProfScope prof(K_REDUCE, (double)n * splits * 4.0);
     reduce_slabs(workspace, splits, n, dW, n, accumulate);
 }
@@ -389,15 +401,17 @@ void mlp_forward(MLP* mlp, const PitchedInput& in) {
 
 // accumulate: 1 = add to the gradient buffers (the reference's contract: zero_gradients_mlp first),
 //             0 = overwrite them (saves the memset when the caller knows they are stale)
-void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int accumulate) {
+void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int accumulate, ReduceQueue* queue) {
     const long B = mlp->batch_size;
     const int in = mlp->input_dim, hid = mlp->hidden_dim, out = mlp->output_dim;
+    float* ws_output = (float*)mlp->d_workspace;
+    float* ws_hidden = (float*)((char*)mlp->d_workspace + output_layer_slab_bytes(hid, out, (int)B));
     if (skinny_ok(hid, out)) {
         skinny_backward(mlp->d_error_output, mlp->d_layer_preact, mlp->d_W2, mlp->d_error_hidden, mlp->d_W2_grad, B,
-                        hid, out, mlp->d_workspace, accumulate);
+                        hid, out, ws_output, accumulate, false, queue);
     } else {
         weight_gradient(mlp->d_error_output, out, mlp->d_layer_postact, hid, hid, B, mlp->d_W2_grad,
-                        mlp->d_workspace, accumulate, mlp->matrix_math);
+                        ws_output, accumulate, mlp->matrix_math, false, queue);
         GemmArgs g = {};
         g.A = mlp->d_error_output; g.lda = out; g.a_kc = 1;
         g.B = mlp->d_W2; g.ldb = hid; g.b_kc = 0;
@@ -407,8 +421,8 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
         ProfScope prof(K_GEMM_DGRAD, 2.0 * (double)B * hid * out);
         if (mlp_gemm(g, mlp->matrix_math) != NERF_OK) { fprintf(stderr, "backward_pass_mlp: hidden error failed\n"); exit(EXIT_FAILURE); }
     }
-    weight_gradient(mlp->d_error_hidden, hid, d_X, in, ld_X, B, mlp->d_W1_grad, mlp->d_workspace, accumulate,
-                    mlp->matrix_math);
+    weight_gradient(mlp->d_error_hidden, hid, d_X, in, ld_X, B, mlp->d_W1_grad, ws_hidden, accumulate,
+                    mlp->matrix_math, false, queue);
     if (d_grad_X) {
         GemmArgs g = {};
         g.A = mlp->d_error_hidden; g.lda = hid; g.a_kc = 1;
@@ -534,7 +548,9 @@ void zero_gradients_mlp(MLP* mlp) {
 
 void backward_pass_mlp(MLP* mlp, float* d_X, float* d_grad_X) {
     require_activations(mlp, "backward_pass_mlp", true);
-    mlp_backward(mlp, d_X, mlp->input_dim, d_grad_X, 1);
+    ReduceQueue sums;  // the two weight gradients' slab sums as one launch
+    mlp_backward(mlp, d_X, mlp->input_dim, d_grad_X, 1, &sums);
+    sums.flush();
     NERF_HIP_CHECK(hipGetLastError());
 }
 

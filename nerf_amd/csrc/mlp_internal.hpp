@@ -23,7 +23,9 @@ struct PitchedInput {
 void mlp_forward(MLP* mlp, const float* d_X);
 void mlp_forward(MLP* mlp, const PitchedInput& in);
 // accumulate = 1: add to the gradient buffers; 0: overwrite them.  ld_X = floats between rows of d_X.
-void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int accumulate);
+// queue: where the slab sums of the two weight gradients wait (they use separate halves of the MLP's
+// workspace); nullptr: summed before the call returns its launches.
+void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int accumulate, ReduceQueue* queue = nullptr);
 
 // Pieces of the two functions above, for callers that arrange the layers themselves (the trainer's
 // fused linear pair).  `math`: MATH_EXACT or MATH_SPLIT_BF16 (shapes the split kernels do not take
@@ -35,7 +37,7 @@ bool skinny_ok(int hidden, int out_dim);
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]; workspace >= wgrad_slab_bytes(...)
 // operands_split: Err and Act hold split words (common.hpp); needs math == MATH_SPLIT_BF16
 void weight_gradient(const float* Err, int rows_out, const float* Act, int cols, int ld_act, long batch, float* dW,
-                     float* workspace, int accumulate, int math, bool operands_split = false);
+                     float* workspace, int accumulate, int math, bool operands_split = false, ReduceQueue* queue = nullptr);
 size_t wgrad_slab_bytes(int rows_out, int cols, long batch);
 
 }  // namespace nerf

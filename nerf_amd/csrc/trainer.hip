@@ -111,8 +111,7 @@ int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int a
     const NerfTrainerConfig& c = tr->cfg;
     const int R = c.rays_per_batch, S = c.num_samples;
     const bool spacing = c.quadrature == NERF_QUADRATURE_SPACING;
-    float* loss = tr->d_grads + tr->n_params;
-    if (!accumulate && hipMemsetAsync(loss, 0, 4 * sizeof(float), stream()) != hipSuccess) return NERF_ERR_HIP;
+    float* loss = tr->d_grads + tr->n_params;  // the three floats behind it stay zero from nerf_trainer_create on
     int rc;
     {
         ProfScope prof(K_COMPOSITE_FWD, (double)R * S * 16.0 + (double)R * 36.0);
@@ -124,7 +123,7 @@ int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int a
     if (rc != NERF_OK) return rc;
     {
         ProfScope prof(K_LOSS, (double)R * 12.0);
-        rc = nerf_loss_accumulate(tr->d_err, R, loss);
+        rc = loss_sum(tr->d_err, R, loss, accumulate);  // a first micro-batch overwrites: no memset launch
     }
     if (rc != NERF_OK) return rc;
     ProfScope prof(K_COMPOSITE_BWD, (double)R * S * 32.0 + (double)R * 12.0);
@@ -197,8 +196,9 @@ int after_forward_fused(NerfTrainer* tr, int accumulate) {
     skinny_forward(m2->d_layer_preact, m2->d_W2, m2->d_layer_output, N, H, O, true);
     const int rc = composite_and_gradient(tr, m2->d_layer_output, m2->d_error_output, accumulate);
     if (rc != NERF_OK) return rc;
+    ReduceQueue sums;  // the output layer's and the encoding layer's slab sums: one launch at the end
     skinny_backward(m2->d_error_output, m2->d_layer_preact, m2->d_W2, m2->d_error_hidden, m2->d_W2_grad, N, H, O,
-                    m2->d_workspace, accumulate, tr->words != 0);
+                    m2->d_workspace, accumulate, tr->words != 0, &sums);
     weight_gradient(m2->d_error_hidden, H, m1->d_layer_postact, H, H, N, tr->d_dwc, tr->d_pair_ws, 0, math,
                     tr->words != 0);
     {
@@ -227,7 +227,8 @@ int after_forward_fused(NerfTrainer* tr, int accumulate) {
         must(mlp_gemm(g, math), "fused pair, backward");
     }
     weight_gradient(m1->d_error_hidden, H, tr->d_pe, m1->input_dim, tr->pe_ld, N, m1->d_W1_grad, m1->d_workspace,
-                    accumulate, math, tr->words != 0);
+                    accumulate, math, tr->words != 0, &sums);
+    sums.flush();
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
@@ -238,8 +239,12 @@ int after_forward(NerfTrainer* tr, int accumulate) {
     mlp_forward(tr->mlp2, tr->mlp1->d_layer_output);
     const int rc = composite_and_gradient(tr, tr->mlp2->d_layer_output, tr->mlp2->d_error_output, accumulate);
     if (rc != NERF_OK) return rc;
-    mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp2->input_dim, tr->mlp1->d_error_output, accumulate);
-    mlp_backward(tr->mlp1, tr->d_pe, tr->pe_ld, nullptr, accumulate);
+    // the four weight gradients' slab sums wait for each other and go as one launch: nothing reads a
+    // gradient before the step's backward pass is over
+    ReduceQueue sums;
+    mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp2->input_dim, tr->mlp1->d_error_output, accumulate, &sums);
+    mlp_backward(tr->mlp1, tr->d_pe, tr->pe_ld, nullptr, accumulate, &sums);
+    sums.flush();
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
