@@ -39,6 +39,13 @@ CASES = [
     (300, 256, 16, 1, 1),      # a single 16-step K-tile on the DMA path
     (300, 256, 48, 1, 0),      # odd number of 16-step K-tiles (the loop is unrolled by two)
     (257, 130, 144, 1, 1),     # K a multiple of 16 but not of 32, ragged rows and columns
+    # the reference's own batch (16 rays x 128 samples, train.c:16-17): one 64x64 tile per CU; then
+    # ragged in M and N, and 320 tiles
+    (2048, 512, 512, 1, 1),
+    (2048, 512, 512, 1, 0),
+    (2048, 512, 160, 1, 1),
+    (2000, 500, 96, 1, 0),
+    (2560, 512, 64, 1, 1),
     # the cases above are small enough for 64x64 tiles; these two fill the chip and take 128x128 ones
     (32770, 512, 96, 1, 1),
     (32770, 500, 80, 1, 0),
