@@ -118,28 +118,45 @@ __global__ __launch_bounds__(256) void head_backward_bf16_kernel(const float* __
         }
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(rows, r0 + rows_per_block);
-    for (long row = r0 + rsub; row < r1; row += rpi) {
-        float e[OUT];
+    // HB_UNROLL points per thread and iteration, every load issued before the first value is used: one
+    // 16-byte load in flight per thread left this kernel waiting on memory between bursts of arithmetic
+    // (about 26 vector instructions per value).  Points are taken in the same order as one at a time,
+    // so the column sums are the same bits.
+    constexpr int HB_UNROLL = 4;
+    for (long row = r0 + rsub; row < r1; row += (long)rpi * HB_UNROLL) {
+        u32x4 px[HB_UNROLL];
+        float e[HB_UNROLL][OUT];
 #pragma unroll
-        for (int o = 0; o < OUT; o++) e[o] = E[row * OUT + o];
-        float x[8];
-        unpack8(*reinterpret_cast<const u32x4*>(pre + row * hidden + cg * 8), x);
-        float eh[8];
+        for (int u = 0; u < HB_UNROLL; u++) {
+            const long rr = row + (long)u * rpi;
+            const long rc = rr < r1 ? rr : r1 - 1;  // clamp: past the end nothing is stored or summed
+            px[u] = *reinterpret_cast<const u32x4*>(pre + rc * hidden + cg * 8);
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            // hardware exp2/rcp (about 1 ulp each): far inside bf16's 8 bits
-            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x[k] * -1.44269504088896340736f));
-            const float hact = x[k] * sg;
-            const float d = sg + x[k] * sg * (1.0f - sg);
-            float back = e[0] * w2[0][k];
-#pragma unroll
-            for (int o = 1; o < OUT; o++) back += e[o] * w2[o][k];
-            eh[k] = back * d;
-#pragma unroll
-            for (int o = 0; o < OUT; o++) acc[o][k] += e[o] * hact;
+            for (int o = 0; o < OUT; o++) e[u][o] = rr < r1 ? E[rc * OUT + o] : 0.f;
         }
-        const u32x4 out = {pack2(eh[0], eh[1]), pack2(eh[2], eh[3]), pack2(eh[4], eh[5]), pack2(eh[6], eh[7])};
-        *reinterpret_cast<u32x4*>(EH + row * hidden + cg * 8) = out;
+#pragma unroll
+        for (int u = 0; u < HB_UNROLL; u++) {
+            const long rr = row + (long)u * rpi;
+            if (rr >= r1) break;
+            float x[8];
+            unpack8(px[u], x);
+            float eh[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                // hardware exp2/rcp (about 1 ulp each): far inside bf16's 8 bits
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x[k] * -1.44269504088896340736f));
+                const float hact = x[k] * sg;
+                const float d = sg + x[k] * sg * (1.0f - sg);
+                float back = e[u][0] * w2[0][k];
+#pragma unroll
+                for (int o = 1; o < OUT; o++) back += e[u][o] * w2[o][k];
+                eh[k] = back * d;
+#pragma unroll
+                for (int o = 0; o < OUT; o++) acc[o][k] += e[u][o] * hact;
+            }
+            const u32x4 out = {pack2(eh[0], eh[1]), pack2(eh[2], eh[3]), pack2(eh[4], eh[5]), pack2(eh[6], eh[7])};
+            *reinterpret_cast<u32x4*>(EH + rr * hidden + cg * 8) = out;
+        }
     }
     float* slab = slabs + (size_t)blockIdx.x * OUT * hidden;
 #pragma unroll
