@@ -135,6 +135,30 @@ def test_virtual_ranks_of_the_c_driver_train_the_global_batch(gpu, tmp_path, vir
             assert np.abs(a[name] - b[name]).max() <= 0.02 * lr, (k, name)
 
 
+def test_the_65536_ray_batch_as_eight_virtual_ranks(gpu, tmp_path):
+    """The data-parallel configuration at full size on one GPU: a global batch of 65 536 rays x 128 samples
+    (8.4 M points) as ONE batch, and as the eight 8192-ray shards that eight ranks would take of it
+    (--virtual-ranks 8 --rays 8192, one AdamW step with the global divisor): same rays, same losses, and
+    after three steps the same weights to a small fraction of the step size"""
+    from test_gpu_driver import read_checkpoint, write_scene
+    write_scene(str(tmp_path))
+    common = ["--data", str(tmp_path), "--images", "4", "--samples", "128", "--batches", "3", "--seed", "5",
+              "--log-every", "1", "--render-every", "0"]
+    outs = {}
+    for tag, extra in (("whole", ["--rays", "65536"]), ("shards", ["--rays", "8192", "--virtual-ranks", "8"])):
+        p = subprocess.run([TRAIN] + common + extra + ["--save", tag], cwd=str(tmp_path), capture_output=True, text=True,
+                           timeout=170)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        outs[tag] = _losses(p.stdout)
+        assert len(outs[tag]) == 3 and all(np.isfinite(outs[tag]))
+    np.testing.assert_allclose(outs["shards"], outs["whole"], rtol=1e-5)
+    for k in (1, 2):
+        a, b = read_checkpoint(tmp_path / f"whole_nerf_model{k}.bin"), read_checkpoint(tmp_path / f"shards_nerf_model{k}.bin")
+        assert a["t"] == b["t"] == 3
+        for name in ("W1", "W2"):
+            assert np.abs(a[name] - b[name]).max() <= 0.02 * 1e-4, (k, name)
+
+
 def test_virtual_ranks_at_the_reference_widths_through_the_python_mirror(gpu, oracle_fast):
     """the same property through the C ABI directly, at the reference's widths (150-512-512-512-4,
     128 samples): 8 shards of 64 rays, cut from one global draw of 512 rays, against one 512-ray batch:
