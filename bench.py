@@ -701,6 +701,12 @@ def main():
             for rays_ref in (16, 64, 256):
                 out["secondary"][f"reference_config_{rays_ref}x{S}"] = reference_config_rate(
                     lib, host, dds, rays_ref, S, 2000 if rays_ref <= 64 else 600, 200, with_cpu=(rays_ref == 16))
+            # the data-parallel configuration's GLOBAL batch (65 536 rays; 8192 per GPU on eight) as one batch on
+            # this one GPU: what eight ranks train per step, without the all-reduce (8.4 M points, ~125 GB)
+            big = optin_train_rate(lib, host, dds, 65536, S, 4, 1, False, False)
+            big["config"] = {"workload": f"full training step on the 8-GPU configuration's global batch, 65536 rays x {S} "
+                                         "samples as ONE batch on one GPU, fp32"}
+            out["secondary"]["global_batch_65536_rays_on_one_gpu"] = big
             for key, sp, fu in (("train_split_bf16_products", True, False), ("train_linear_pair_fused", False, True),
                                 ("train_split_bf16_products_linear_pair_fused", True, True)):
                 out["secondary"][key] = optin_train_rate(lib, host, dds, R, S, 20, 5, sp, fu)
