@@ -637,16 +637,20 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, unsigned off_lo, uns
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int WM, int WN, int MI, int NI, int CUR>
-__device__ __forceinline__ void wg_tile(char (&lds)[2][BKH * (WM * MI + WN * NI) * 64],
+// One K-tile: the LDS-DMA of tile `next` into `nxt` is issued, then tile `cur` is multiplied.  The two
+// buffers are declared not to alias: the compiler otherwise makes every LDS read wait for all
+// outstanding LDS-DMA (it cannot tell which bytes a transfer writes), i.e. for the tile just asked for,
+// and the transfer would not overlap the products at all.
+template <int WM, int WN, int MI, int NI>
+__device__ __forceinline__ void wg_tile(const char* __restrict__ cur, char* __restrict__ nxt,
                                         const RowTileLoader<WM * MI * 32, WM * WN * 64>& da,
                                         const RowTileLoader<WN * NI * 32, WM * WN * 64>& db, f32x16 (&acc)[MI][NI],
                                         int next, int wave, const unsigned (&offA)[MI][2], const unsigned (&offB)[NI][2]) {
     constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32, ATILE = BKH * BM_ * 2;
-    da.issue(lds[CUR ^ 1], next, wave);
-    db.issue(lds[CUR ^ 1] + ATILE, next, wave);
-    const char* TA = lds[CUR];
-    const char* TB = lds[CUR] + ATILE;
+    da.issue(nxt, next, wave);
+    db.issue(nxt + ATILE, next, wave);
+    const char* TA = cur;
+    const char* TB = cur + ATILE;
     bf16x8 fa[2][MI], fb[2][NI];
 #pragma unroll
     for (int i = 0; i < MI; i++) fa[0][i] = tr_frag<BM_>(TA, offA[i][0], offA[i][1], 0);
@@ -668,6 +672,7 @@ __device__ __forceinline__ void wg_tile(char (&lds)[2][BKH * (WM * MI + WN * NI)
             for (int ni = 0; ni < NI; ni++)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[c][mi], fb[c][ni], acc[mi][ni], 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's pieces of the next tile have landed
     __syncthreads();
 }
 
@@ -716,10 +721,10 @@ __global__ __launch_bounds__(WM * WN * 64, 512 / (WM * WN * 64)) void wgrad_bf16
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nkt; kt += 2) {
-        wg_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt + 1, wave, offA, offB);
-        wg_tile<WM, WN, MI, NI, 1>(lds, da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, offA, offB);
+        wg_tile<WM, WN, MI, NI>(lds[0], lds[1], da, db, acc, kt + 1, wave, offA, offB);
+        wg_tile<WM, WN, MI, NI>(lds[1], lds[0], da, db, acc, kt + 2 < nkt ? kt + 2 : kt + 1, wave, offA, offB);
     }
-    if (kt < nkt) wg_tile<WM, WN, MI, NI, 0>(lds, da, db, acc, kt, wave, offA, offB);
+    if (kt < nkt) wg_tile<WM, WN, MI, NI>(lds[0], lds[1], da, db, acc, kt, wave, offA, offB);
     epilogue<MI, NI>(p, acc, m0, n0, split, wm * MI * 32, wn * NI * 32, lane, BM_);
 }
 
