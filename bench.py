@@ -368,9 +368,9 @@ def bf16_workload(args, lib, torch):
         "gemm_wgrad": "wgrad_bf16_kernel<2, 4, 4, 2> (v_mfma_f32_32x32x16_bf16, 256x256 tiles, ds_read_b64_tr_b16 operands)",
     }
     # HBM side of the same products: operands read once, results written once, per point of a micro-batch
-    # (bf16, 2 bytes): enc->pre1,act1; act1->y1; y1->pre2,act2; eh2->dy1; dy1 (+pre1)->eh1; three weight gradients
+    # (bf16, 2 bytes): enc->pre1,act1; act1->y1; y1->pre2; eh2->dy1; dy1 (+pre1)->eh1; three weight gradients
     pe_ld = 192
-    elems_per_point = ((pe_ld + 2 * hidden) + (hidden + inter) + (inter + 2 * hidden) + (hidden + inter)
+    elems_per_point = ((pe_ld + 2 * hidden) + (hidden + inter) + (inter + hidden) + (hidden + inter)
                        + (inter + 2 * hidden) + 2 * (hidden + inter) + (hidden + pe_ld))
     product_bytes = 2.0 * elems_per_point * micro * S * n_micro * steps
     traffic, _, traffic_file = pmc_traffic("gemm_bf16_nt8_kernel<1>", "bf16_cfg5_")
@@ -385,8 +385,7 @@ def bf16_workload(args, lib, torch):
         "roofline": {"bound": "mfma", "kernel": labels.get(dom, dom), "achieved": achieved,
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
                      "traffic": traffic,
-                     "traffic_unit": "HBM-side bytes per launch of gemm_bf16_nt8_kernel<swish> (L2 fetches x2 + writes), "
-                                     "average of its two positions in a micro-batch",
+                     "traffic_unit": "HBM-side bytes per launch of gemm_bf16_nt8_kernel<swish> (L2 fetches x2 + writes)",
                      "traffic_source": traffic_file and f"{traffic_file}: counters of an earlier run of this workload",
                      "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12, "gemm_share_of_step": all_ms / (el * 1e3),
                      "products_against_hbm": {
@@ -394,8 +393,8 @@ def bf16_workload(args, lib, torch):
                          "unit": "GB/s", "frac": product_bytes / (all_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                          "algorithmic_bytes_per_point": 2.0 * elems_per_point,
                          "flop_per_byte": all_work / product_bytes,
-                         "note": "these products sit between the roofs: about 236 FLOP per byte against a machine "
-                                 "balance of about 400 (2.5 PFLOP/s over 6.3 TB/s a copy reaches)"},
+                         "note": f"these products sit between the roofs: about {all_work / product_bytes:.0f} FLOP per byte "
+                                 "against a machine balance of about 400 (2.5 PFLOP/s over 6.3 TB/s a copy reaches)"},
                      "kernels": {k: {"ms_per_step": v[0] / steps, "launches_per_step": v[1] / steps} for k, v in prof.items()
                                  if v[1] > 0}},
     })

@@ -288,7 +288,8 @@ const float* nerf_trainer_buffer(NerfTrainer* tr, int which);
 int nerf_trainer_encoding_pitch(const NerfTrainer* tr);
 /* bf16 precision only: 16-bit buffers of the last step, [N][...]: 0 encoding [pitch], 1 layer-1
  * pre-activation (after the backward pass: its error), 2 layer-1 activation, 3 first MLP's output
- * (after backward: its gradient), 4 layer-3 pre-activation, 5 layer-3 activation (after backward: error) */
+ * (after backward: its gradient), 4 layer-3 pre-activation, 5 the error entering layer 3 (written by the
+ * backward pass; the layer-3 activation itself is never stored, its readers form it from buffer 4) */
 const unsigned short* nerf_trainer_buffer_bf16(NerfTrainer* tr, int which);
 
 /* ---- data parallelism over rays: RCCL from C.  No counterpart in the reference, which is single-GPU

@@ -59,6 +59,7 @@ enum GemmEpilogue {
     EPI_SWISH = 1,        // C[m][n] = acc (skipped when C == nullptr) ; C2[m][n] = swish(acc)
     EPI_DSWISH_MUL = 2,   // C[m][n] = acc * swish'(AUX[m][n])
     EPI_SPLITK = 3,       // slab[split][m][n] = partial acc   (reduced by reduce_slabs)
+    EPI_SWISH_HEAD = 4,   // bf16 products only: C[m][n] = acc and, per 64 columns, the 4-wide output layer's partial sums
 };
 
 struct GemmArgs {
@@ -136,8 +137,16 @@ struct GemmBf16Args {
     int M, N, K;        // K a multiple of 64, N a multiple of 8
     int lda, ldb, ldc;  // multiples of 8 (rows move in 16-byte pieces)
     int epilogue;
+    // EPI_SWISH_HEAD: head_w [4][head_ld] fp32 (rounded to bf16 as it is read), head_partial
+    // [ceil(N / 64)][M][4] fp32: block b, row m holds sum over columns 64 b .. 64 b + 63 of
+    // bf16(swish(C[m][n])) * bf16(head_w[o][n]) for o = 0..3
+    const float* head_w;
+    int head_ld;
+    float* head_partial;
 };
 int gemm_bf16_nt(const GemmBf16Args& args);
+// whether gemm_bf16_nt takes EPI_SWISH_HEAD for this shape (the persistent 256x256 kernel only)
+bool gemm_bf16_nt_head_supported(long M, int N, int K);
 WgradPlan plan_weight_gradient_bf16(int rows_out, int cols, long batch);
 // dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols]; fp32 result; workspace as planned
 int weight_gradient_bf16(const bf16_t* Err, int rows_out, int ld_err, const bf16_t* Act, int cols, int ld_act,

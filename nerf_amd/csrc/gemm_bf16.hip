@@ -112,6 +112,7 @@ __device__ __forceinline__ void nt_tile(float (&lds)[2][(WM * MI + WN * NI) * 32
 // The three steps of that epilogue.  `stage` is the wavefront's [ROWS][16 chunks of 8 bytes] image.
 struct NtRows {
     __amdgpu_buffer_rsrc_t rC, rC2, rAUX;
+    __amdgpu_buffer_rsrc_t rP;  // EPI_SWISH_HEAD: this wavefront's 64-column block of the output layer's partial sums
     unsigned col_off, row_bytes;
     int row0;  // first row of the wavefront's tile inside the workgroup's panel
 };
@@ -133,6 +134,9 @@ __device__ __forceinline__ NtRows nt_rows(const GemmBf16Args& p, int m0, int pan
     r.col_off = (ncol + 7 < p.N) ? (unsigned)ncol * 2u : OOR;
     r.row_bytes = (unsigned)p.ldc * 2u;
     r.row0 = row0;
+    if (EPI == EPI_SWISH_HEAD)
+        r.rP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.head_partial + ((size_t)(ncol0 >> 6) * p.M + m0) * 4), 0,
+                                                 ncol0 < p.N ? (unsigned)rows_here * 16u : 0u, 0x00020000);
     return r;
 }
 
@@ -171,6 +175,54 @@ __device__ __forceinline__ void nt_stage_to_global(const NtRows& r, const u32x2*
             for (int e = 0; e < 4; e++) act[e] = pack_bf16(swish_f(bf16_lo(out[e])), swish_f(bf16_hi(out[e])));
             __builtin_amdgcn_raw_buffer_store_b128(act, r.rC2, voff, 0, 0);
         }
+    }
+}
+
+// lane l receives src from lane l - N of its row of 16 (zero from outside the row)
+template <int N>
+__device__ __forceinline__ float row_shr_or_zero(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x110 + N, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, true));
+}
+
+// stage -> global rows of the pre-activation, and the 4-wide output layer's share of these 64 columns:
+// the activation (swish of the ROUNDED pre-activation, rounded to bf16 -- the values EPI_SWISH stores)
+// never leaves the registers; hw[o][k] is the output layer's weight for this lane's column k.  The
+// eight lanes of a row add up in a fixed order; lane 7 of each eight stores the row's four sums.
+template <int ROWS>
+__device__ __forceinline__ void nt_stage_to_global_head(const NtRows& r, const u32x2* stage, int lane, const float (&hw)[4][8]) {
+    const u32x4* stage16 = reinterpret_cast<const u32x4*>(stage);
+    const int rsub = lane >> 3, c16 = lane & 7;
+#pragma unroll
+    for (int it = 0; it < ROWS / 8; it++) {
+        const int row = it * 8 + rsub;
+        const unsigned voff = r.col_off == OOR ? OOR : (unsigned)(r.row0 + row) * r.row_bytes + r.col_off;
+        const u32x4 raw = stage16[row * 8 + (c16 ^ ((row & 15) >> 1))];
+        const u32x4 sw = {raw[2], raw[3], raw[0], raw[1]};
+        const u32x4 out = (row & 1) ? sw : raw;
+        __builtin_amdgcn_raw_buffer_store_b128(out, r.rC, voff, 0, 0);
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const unsigned w = pack_bf16(swish_f(bf16_lo(out[e])), swish_f(bf16_hi(out[e])));
+            a[2 * e] = bf16_lo(w);
+            a[2 * e + 1] = bf16_hi(w);
+        }
+        f32x4 s;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float t = a[0] * hw[o][0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) t += a[k] * hw[o][k];
+            t += quad_perm<0xb1>(t);      // lanes l ^ 1
+            t += quad_perm<0x4e>(t);      // lanes l ^ 2
+            t += row_shr_or_zero<4>(t);   // lanes 4..7 of each eight now hold the row's sum
+            s[o] = t;
+        }
+        if (c16 == 7) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), r.rP, (unsigned)(r.row0 + row) * 16u, 0, 0);
     }
 }
 
@@ -418,9 +470,9 @@ __device__ __forceinline__ void nt8_slice(char* lds, const Nt8Tile& cur, const N
 }
 
 // stores per wavefront in the epilogue of one tile: 4 passes of 4 rows-of-lines, twice that when the
-// activation is written beside the pre-activation
+// activation (or the output layer's partial sums) is written beside the pre-activation
 template <int EPI>
-constexpr int nt8_stores() { return EPI == EPI_SWISH ? 32 : 16; }
+constexpr int nt8_stores() { return (EPI == EPI_SWISH || EPI == EPI_SWISH_HEAD) ? 32 : 16; }
 
 // A finished tile leaves through the wavefront's own 4 KB of LDS beside the ring, 32 points at a time
 // (the ring keeps running underneath: the next tile's first slices are landing meanwhile).  The
@@ -449,6 +501,22 @@ __device__ __forceinline__ void nt8_store(const GemmBf16Args& p, f32x4acc (&acc)
         }
     };
     if (EPI == EPI_DSWISH_MUL) fetch_aux(0);
+    float hw[4][8];
+    if (EPI == EPI_SWISH_HEAD) {  // the output layer's weights of this lane's 8 columns, rounded as the matrix cores would read them
+        const int ncol = n0 + wn * 64 + c16 * 8;
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_w, 0, (unsigned)(4 * p.head_ld) * 4u, 0x00020000);
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const unsigned woff = ncol + 7 < p.N ? (unsigned)(o * p.head_ld + ncol) * 4u : OOR;
+            const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, woff, 0, 0));
+            const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, woff == OOR ? OOR : woff + 16u, 0, 0));
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                hw[o][k] = bf16_lo(pack_bf16(lo[k], 0.f));
+                hw[o][4 + k] = bf16_lo(pack_bf16(hi[k], 0.f));
+            }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         if (EPI == EPI_DSWISH_MUL) {
@@ -470,7 +538,8 @@ __device__ __forceinline__ void nt8_store(const GemmBf16Args& p, f32x4acc (&acc)
                              acc[ni][2 * q + h][2], acc[ni][2 * q + h][3]);
         NtRows rq = r;
         rq.row0 = wm * 128 + q * 32;
-        nt_stage_to_global<32, EPI>(rq, stage, lane);
+        if (EPI == EPI_SWISH_HEAD) nt_stage_to_global_head<32>(rq, stage, lane, hw);
+        else nt_stage_to_global<32, EPI>(rq, stage, lane);
     }
 }
 
@@ -750,7 +819,12 @@ __global__ __launch_bounds__(256) void convert_bf16_kernel(const float* __restri
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// the 256x256 shape when the product is large enough to fill the chip with it
+inline bool nt_big_tiles(long M, int N) { return N > 128 && ((M + 255) / 256) * ((N + 255) / 256) >= 256; }
+
 }  // namespace
+
+bool gemm_bf16_nt_head_supported(long M, int N, int K) { return nt_big_tiles(M, N) && K >= 128 && K % BKH == 0 && N % 8 == 0; }
 
 int gemm_bf16_nt(const GemmBf16Args& g) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return NERF_ERR_ARG;
@@ -758,11 +832,15 @@ int gemm_bf16_nt(const GemmBf16Args& g) {
     if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N) return NERF_ERR_ARG;
     if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || !aligned16(g.C2) || !aligned16(g.AUX))
         return NERF_ERR_ARG;
-    if (g.epilogue != EPI_STORE && g.epilogue != EPI_SWISH && g.epilogue != EPI_DSWISH_MUL) return NERF_ERR_ARG;
+    if (g.epilogue != EPI_STORE && g.epilogue != EPI_SWISH && g.epilogue != EPI_DSWISH_MUL && g.epilogue != EPI_SWISH_HEAD)
+        return NERF_ERR_ARG;
+    if (g.epilogue == EPI_SWISH_HEAD &&
+        (!gemm_bf16_nt_head_supported(g.M, g.N, g.K) || !g.C || !g.head_w || !g.head_partial || g.head_ld < g.N ||
+         g.head_ld % 4 != 0 || !aligned16(g.head_w) || !aligned16(g.head_partial)))
+        return NERF_ERR_ARG;
     NtArgs ka;
     ka.g = g;
-    // the 256x256 shape when the product is large enough to fill the chip with it
-    const bool big = g.N > 128 && (long)((g.M + 255) / 256) * ((g.N + 255) / 256) >= 256;
+    const bool big = nt_big_tiles(g.M, g.N);
     const int tile = big ? 256 : 128;
     // a tile's rows of A, B and C are addressed with 32-bit byte offsets from the tile's first row
     const int ld_max = g.lda > g.ldb ? (g.lda > g.ldc ? g.lda : g.ldc) : (g.ldb > g.ldc ? g.ldb : g.ldc);
@@ -780,6 +858,7 @@ int gemm_bf16_nt(const GemmBf16Args& g) {
         if (wgs > grid) wgs = grid;
         const dim3 gr((unsigned)wgs), bl(512);
         if (g.epilogue == EPI_SWISH) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_SWISH>, gr, bl, 0, stream(), ka);
+        else if (g.epilogue == EPI_SWISH_HEAD) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_SWISH_HEAD>, gr, bl, 0, stream(), ka);
         else if (g.epilogue == EPI_DSWISH_MUL) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_DSWISH_MUL>, gr, bl, 0, stream(), ka);
         else hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_STORE>, gr, bl, 0, stream(), ka);
     } else if (big)

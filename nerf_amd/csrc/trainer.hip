@@ -542,7 +542,7 @@ const unsigned short* nerf_trainer_buffer_bf16(NerfTrainer* tr, int which) {
         case 2: return tr->bf->act1;
         case 3: return tr->bf->y1;
         case 4: return tr->bf->pre2;
-        case 5: return tr->bf->act2;
+        case 5: return tr->bf->eh2;
         default: return nullptr;
     }
 }

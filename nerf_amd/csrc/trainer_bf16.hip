@@ -6,13 +6,17 @@
 //   enc   = bf16(encoding)                          [N][192]  (150 used, zero tail)
 //   pre1  = bf16(enc W1a^T), act1 = bf16(swish(pre1))
 //   y1    = bf16(act1 W2a^T)
-//   pre2  = bf16(y1 W1b^T),  act2 = bf16(swish(pre2))
+//   pre2  = bf16(y1 W1b^T)                           (act2 = bf16(swish(pre2)) is never stored: the output
+//                                                     layer's forward sums are formed where pre2 is -- in
+//                                                     that product's epilogue for large batches, else by a
+//                                                     kernel that reads pre2 -- and its backward pass
+//                                                     reads pre2 as well)
 //   raw   = act2 bf16(W2b)^T                         fp32 [N][4] -> compositing, loss, its gradient (fp32)
 //   eh2   = bf16((draw bf16(W2b)) .* swish'(pre2));  dW2b += draw^T swish(pre2)
 //   dW1b += eh2^T y1;   dy1 = bf16(eh2 W1b);   dW2a += dy1^T act1
 //   eh1   = bf16((dy1 W2a) .* swish'(pre1));    dW1a += eh1^T enc
 //
-// Buffers are reused once dead (eh2 over act2, dy1 over y1, eh1 over pre1).  Weight gradients are
+// Buffers are reused once dead (dy1 over y1, eh1 over pre1).  Weight gradients are
 // fp32 sums written into the trainer's gradient arena, exactly where the fp32 step leaves them.
 #include "mlp_internal.hpp"
 #include "trainer_bf16.hpp"
@@ -41,11 +45,18 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
 }
 
-// raw[n][o] = sum_h act[n][h] * bf16(W2[o][h]).  A 16-lane group takes HEAD_ROWS points at a time, 8
-// features per lane and step, so every weight read from LDS is used HEAD_ROWS times.
+// same sigmoid as the matrix products' epilogues (hardware exp2 and reciprocal, about 1 ulp each)
+__device__ __forceinline__ float swish_bf16(float x) {
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+    return bf16_round(x * sg);
+}
+
+// raw[n][o] = sum_h act[n][h] * bf16(W2[o][h]), with act = bf16(swish(pre)) formed here when FROM_PRE.
+// A 16-lane group takes HEAD_ROWS points at a time, 8 features per lane and step, so every weight
+// read from LDS is used HEAD_ROWS times.
 constexpr int HEAD_ROWS = 4;
 
-template <int OUT>
+template <int OUT, bool FROM_PRE>
 __global__ __launch_bounds__(256) void head_forward_bf16_kernel(const bf16_t* __restrict__ act,
                                                                 const float* __restrict__ W2, float* __restrict__ Y,
                                                                 long rows, int hidden) {
@@ -66,6 +77,10 @@ __global__ __launch_bounds__(256) void head_forward_bf16_kernel(const bf16_t* __
             for (int r = 0; r < HEAD_ROWS; r++) {
                 const long row = row0 + r < rows ? row0 + r : rows - 1;  // clamp: the extra rows are not stored
                 unpack8(*reinterpret_cast<const u32x4*>(act + row * hidden + c), x[r]);
+                if (FROM_PRE) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) x[r][k] = swish_bf16(x[r][k]);
+                }
             }
 #pragma unroll
             for (int o = 0; o < OUT; o++) {
@@ -93,6 +108,17 @@ __global__ __launch_bounds__(256) void head_forward_bf16_kernel(const bf16_t* __
                 }
         }
     }
+}
+
+// Y[n][0..3] = sum over the column blocks b (in order) of partial[b][n][0..3]: the output layer's sums the
+// second hidden layer's product left per 64 columns
+__global__ __launch_bounds__(256) void head_sum_kernel(const f32x4* __restrict__ partial, int blocks, long rows,
+                                                       f32x4* __restrict__ Y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    f32x4 s = partial[i];
+    for (int b = 1; b < blocks; b++) s += partial[(long)b * rows + i];
+    Y[i] = s;
 }
 
 // eh[n][h] = bf16((sum_o E[n][o] bf16(W2[o][h])) * swish'(pre[n][h]));  slab[o][h] = sum_n E[n][o] swish(pre[n][h])
@@ -212,10 +238,14 @@ Bf16Step* bf16_step_create(int pe_dim, int hidden, int inter, int out_dim, long 
     alloc16(&st->enc, N * st->pe_ld);
     alloc16(&st->pre1, N * hidden); alloc16(&st->act1, N * hidden);
     alloc16(&st->y1, N * inter);
-    alloc16(&st->pre2, N * hidden); alloc16(&st->act2, N * hidden);
+    alloc16(&st->pre2, N * hidden); alloc16(&st->eh2, N * hidden);
     alloc16(&st->w1a, (size_t)hidden * st->pe_ld);
     alloc16(&st->w2a, (size_t)inter * hidden); alloc16(&st->w2aT, (size_t)hidden * inter);
     alloc16(&st->w1b, (size_t)hidden * inter); alloc16(&st->w1bT, (size_t)inter * hidden);
+    // the output layer's partial sums per 64 columns, where the second hidden layer's product forms them
+    if (ok && gemm_bf16_nt_head_supported(points, hidden, inter) &&
+        hipMalloc((void**)&st->head_partial, (size_t)((hidden + 63) / 64) * N * 4 * sizeof(float)) != hipSuccess)
+        ok = false;
     if (ok && hipMalloc((void**)&st->raw, N * out_dim * sizeof(float)) != hipSuccess) ok = false;
     if (ok && hipMalloc((void**)&st->draw, N * out_dim * sizeof(float)) != hipSuccess) ok = false;
     size_t ws = (size_t)plan_weight_gradient_bf16(hidden, pe_dim, points).splits * hidden * pe_dim;
@@ -235,9 +265,9 @@ Bf16Step* bf16_step_create(int pe_dim, int hidden, int inter, int out_dim, long 
 
 void bf16_step_destroy(Bf16Step* st) {
     if (!st) return;
-    hipFree(st->enc); hipFree(st->pre1); hipFree(st->act1); hipFree(st->y1); hipFree(st->pre2); hipFree(st->act2);
+    hipFree(st->enc); hipFree(st->pre1); hipFree(st->act1); hipFree(st->y1); hipFree(st->pre2); hipFree(st->eh2);
     hipFree(st->w1a); hipFree(st->w2a); hipFree(st->w2aT); hipFree(st->w1b); hipFree(st->w1bT);
-    hipFree(st->raw); hipFree(st->draw); hipFree(st->workspace);
+    hipFree(st->raw); hipFree(st->draw); hipFree(st->workspace); hipFree(st->head_partial);
     free(st);
 }
 
@@ -265,14 +295,33 @@ int bf16_step_forward(Bf16Step* st, const float* W2b) {
     const int H = st->hidden, M = st->inter, O = st->out_dim;
     int rc = nt(st->enc, st->pe_ld, st->w1a, st->pe_ld, st->pre1, st->act1, nullptr, H, N, H, st->pe_ld, EPI_SWISH, K_GEMM_FWD);
     if (rc == NERF_OK) rc = nt(st->act1, H, st->w2a, H, st->y1, nullptr, nullptr, M, N, M, H, EPI_STORE, K_GEMM_FWD);
-    if (rc == NERF_OK) rc = nt(st->y1, M, st->w1b, M, st->pre2, st->act2, nullptr, H, N, H, M, EPI_SWISH, K_GEMM_FWD);
+    if (rc != NERF_OK) return rc;
+    if (st->head_partial && (reinterpret_cast<uintptr_t>(W2b) & 15) == 0) {
+        // the output layer rides on the second hidden layer's product: each finished 64-column block leaves
+        // its share of the four sums, and the activation is never written
+        GemmBf16Args g = {};
+        g.A = st->y1; g.B = st->w1b; g.C = st->pre2;
+        g.M = (int)N; g.N = H; g.K = M; g.lda = M; g.ldb = M; g.ldc = H; g.epilogue = EPI_SWISH_HEAD;
+        g.head_w = W2b; g.head_ld = H; g.head_partial = st->head_partial;
+        {
+            ProfScope prof(K_GEMM_FWD, 2.0 * (double)N * H * M);
+            rc = gemm_bf16_nt(g);
+        }
+        if (rc != NERF_OK) return rc;
+        const int blocks = (H + 63) / 64;
+        ProfScope prof(K_SKINNY_FWD, (double)N * (blocks + 1) * O * 4.0);
+        hipLaunchKernelGGL(head_sum_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream(),
+                           reinterpret_cast<const f32x4*>(st->head_partial), blocks, N, reinterpret_cast<f32x4*>(st->raw));
+        return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+    }
+    rc = nt(st->y1, M, st->w1b, M, st->pre2, nullptr, nullptr, H, N, H, M, EPI_STORE, K_GEMM_FWD);
     if (rc != NERF_OK) return rc;
     ProfScope prof(K_SKINNY_FWD, (double)N * (H * 2.0 + O * 4.0));
     long blocks = (N + 16 * HEAD_ROWS * 8 - 1) / (16 * HEAD_ROWS * 8);  // 8 sweeps per workgroup
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((head_forward_bf16_kernel<4>), dim3((unsigned)blocks), dim3(256), (size_t)O * H * sizeof(float),
-                       stream(), st->act2, W2b, st->raw, N, H);
+    hipLaunchKernelGGL((head_forward_bf16_kernel<4, true>), dim3((unsigned)blocks), dim3(256), (size_t)O * H * sizeof(float),
+                       stream(), st->pre2, W2b, st->raw, N, H);
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
@@ -280,7 +329,7 @@ int bf16_step_backward(Bf16Step* st, const float* W2b, float* dW1a, float* dW2a,
                        int accumulate) {
     const long N = st->points;
     const int H = st->hidden, M = st->inter, O = st->out_dim;
-    bf16_t* eh2 = st->act2;  // act2 is dead after the head's forward
+    bf16_t* eh2 = st->eh2;
     {
         const int blocks = head_backward_blocks(N, H);
         const int rpi = 256 / (H / 8);

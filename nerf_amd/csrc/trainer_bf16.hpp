@@ -14,7 +14,8 @@ struct Bf16Step {
     bf16_t* act1;   // [hidden]
     bf16_t* y1;     // [inter]; reused for dy1
     bf16_t* pre2;   // [hidden]
-    bf16_t* act2;   // [hidden]; reused for eh2
+    bf16_t* eh2;    // [hidden]: the error entering the second hidden layer
+    float* head_partial;  // fp32 [hidden / 64][points][out_dim]: the output layer's sums per 64 columns (large batches; else null)
     float* raw;     // fp32 [out_dim]: the MLP's output
     float* draw;    // fp32 [out_dim]: dLoss/d(raw)
     // bf16 copies of the weights as the products read them (refreshed every step)

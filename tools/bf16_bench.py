@@ -66,7 +66,7 @@ def main():
 
     nt("forward  enc -> pre1, act1   (K 192, swish)", bufs["enc"], PE, w["w1a"], bufs["h3"], bufs["h1"], None, H, H, PE, 1)
     nt("forward  act1 -> y1          (K 1024)", bufs["h1"], H, w["w2a"], bufs["m2"], None, None, M, M, H, 0)
-    nt("forward  y1 -> pre2, act2    (K 512, swish)", bufs["m"], M, w["w1b"], bufs["h3"], bufs["h2"], None, H, H, M, 1)
+    nt("forward  y1 -> pre2          (K 512)", bufs["m"], M, w["w1b"], bufs["h3"], None, None, H, H, M, 0)
     nt("backward eh2 -> dy1          (K 1024)", bufs["h2"], H, w["w1bT"], bufs["m2"], None, None, M, M, H, 0)
     nt("backward dy1 -> eh1          (K 512, swish')", bufs["m"], M, w["w2aT"], bufs["h3"], None, bufs["h1"], H, H, M, 2)
     for name, err, ro, act, cols, ld in (("weight gradient eh2^T y1   (1024 x 512)", "h2", H, "m", M, M),
