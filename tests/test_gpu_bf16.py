@@ -182,12 +182,13 @@ class Bf16Pair:
                         axis=1).astype(np.int32)
 
 
-@pytest.mark.parametrize("R,S,hidden,inter", [(8, 32, 128, 64), (64, 256, 1024, 512)])
+@pytest.mark.parametrize("R,S,hidden,inter", [(8, 32, 128, 64), (64, 256, 1024, 512), (257, 255, 256, 128)])
 def test_bf16_step_stage_by_stage(gpu, oracle, R, S, hidden, inter):
     """every kernel of the bf16 step against numpy on the device's own inputs to that stage, so each
     check prices one rounding: bf16 outputs within one bf16 ulp, fp32 sums within fp32 rounding.  The
     second shape is large enough for the persistent 256x256 products, where the output layer's forward
-    sums are formed in the second hidden layer's epilogue instead of by a kernel of their own."""
+    sums are formed in the second hidden layer's epilogue instead of by a kernel of their own; the third
+    takes that path with a last row tile of 255 points and the shortest contraction it accepts (128)."""
     from nerf_amd.api import DeviceArray, Trainer
     p = Bf16Pair(gpu, oracle, R=R, S=S, Lp=4, Ld=2, hidden=hidden, inter=inter)
     R, S, H, M, pe = p.R, p.S, p.H, p.M, p.pe
