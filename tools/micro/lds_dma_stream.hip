@@ -3,6 +3,7 @@
 // every operand byte from two to four workgroups that share an XCD; this measures that pattern alone:
 // no LDS reads, no matrix instructions, only the transfers and counted waits.
 //
+//   hipcc --offload-arch=gfx950 -O3 -o lds_dma_stream lds_dma_stream.hip
 //   ./lds_dma_stream <share> [MB per stream] [passes]   share = workgroups per XCD reading the same stream;
 //                                                        passes > 1 re-reads the stream (a small one stays in the L2)
 //
