@@ -189,11 +189,13 @@ __device__ __forceinline__ float quad_perm(float src) {
 }
 
 // stage -> global rows of the pre-activation, and the 4-wide output layer's share of these 64 columns:
-// the activation (swish of the ROUNDED pre-activation, rounded to bf16 -- the values EPI_SWISH stores)
-// never leaves the registers; hw[o][k] is the output layer's weight for this lane's column k.  The
-// eight lanes of a row add up in a fixed order; lane 7 of each eight stores the row's four sums.
+// the activation (swish of the ROUNDED pre-activation, in fp32: no matrix instruction reads it) never
+// leaves the registers; hw[o][k] is the output layer's weight for this lane's column k.  The eight
+// lanes of a row add up in a fixed order; lane 7 of each eight stores the row's four sums.  Multiply-adds
+// may fuse in here (they may not in the fp32 kernels that share this build's flags).
 template <int ROWS>
 __device__ __forceinline__ void nt_stage_to_global_head(const NtRows& r, const u32x2* stage, int lane, const float (&hw)[4][8]) {
+#pragma clang fp contract(fast)
     const u32x4* stage16 = reinterpret_cast<const u32x4*>(stage);
     const int rsub = lane >> 3, c16 = lane & 7;
 #pragma unroll
@@ -207,9 +209,8 @@ __device__ __forceinline__ void nt_stage_to_global_head(const NtRows& r, const u
         float a[8];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const unsigned w = pack_bf16(swish_f(bf16_lo(out[e])), swish_f(bf16_hi(out[e])));
-            a[2 * e] = bf16_lo(w);
-            a[2 * e + 1] = bf16_hi(w);
+            a[2 * e] = swish_f(bf16_lo(out[e]));
+            a[2 * e + 1] = swish_f(bf16_hi(out[e]));
         }
         f32x4 s;
 #pragma unroll

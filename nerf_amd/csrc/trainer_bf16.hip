@@ -6,13 +6,14 @@
 //   enc   = bf16(encoding)                          [N][192]  (150 used, zero tail)
 //   pre1  = bf16(enc W1a^T), act1 = bf16(swish(pre1))
 //   y1    = bf16(act1 W2a^T)
-//   pre2  = bf16(y1 W1b^T)                           (act2 = bf16(swish(pre2)) is never stored: the output
-//                                                     layer's forward sums are formed where pre2 is -- in
-//                                                     that product's epilogue for large batches, else by a
+//   pre2  = bf16(y1 W1b^T)                           (act2 = swish(pre2) is never stored and never rounded:
+//                                                     no matrix instruction reads it.  The output layer's
+//                                                     forward sums are formed where pre2 is -- in that
+//                                                     product's epilogue for large batches, else by a
 //                                                     kernel that reads pre2 -- and its backward pass
 //                                                     reads pre2 as well)
 //   raw   = act2 bf16(W2b)^T                         fp32 [N][4] -> compositing, loss, its gradient (fp32)
-//   eh2   = bf16((draw bf16(W2b)) .* swish'(pre2));  dW2b += draw^T swish(pre2)
+//   eh2   = bf16((draw bf16(W2b)) .* swish'(pre2));  dW2b += draw^T act2
 //   dW1b += eh2^T y1;   dy1 = bf16(eh2 W1b);   dW2a += dy1^T act1
 //   eh1   = bf16((dy1 W2a) .* swish'(pre1));    dW1a += eh1^T enc
 //
@@ -22,6 +23,11 @@
 #include "trainer_bf16.hpp"
 #include "../../include/nerf_amd.h"
 #include "../../include/nerf_spec.h"
+
+// The vector kernels of this file run beside 16-bit activations and are checked against bounds of that
+// size: multiply-adds are allowed to fuse here (the build's default keeps them apart, which the fp32
+// parity paths need), which takes a third of the instructions out of the output layer's backward kernel.
+#pragma clang fp contract(fast)
 
 namespace nerf {
 namespace {
@@ -46,12 +52,11 @@ __device__ __forceinline__ unsigned pack2(float lo, float hi) {
 }
 
 // same sigmoid as the matrix products' epilogues (hardware exp2 and reciprocal, about 1 ulp each)
-__device__ __forceinline__ float swish_bf16(float x) {
-    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
-    return bf16_round(x * sg);
+__device__ __forceinline__ float swish_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
 }
 
-// raw[n][o] = sum_h act[n][h] * bf16(W2[o][h]), with act = bf16(swish(pre)) formed here when FROM_PRE.
+// raw[n][o] = sum_h act[n][h] * bf16(W2[o][h]), with act = swish(pre) formed here (fp32) when FROM_PRE.
 // A 16-lane group takes HEAD_ROWS points at a time, 8 features per lane and step, so every weight
 // read from LDS is used HEAD_ROWS times.
 constexpr int HEAD_ROWS = 4;
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void head_forward_bf16_kernel(const bf16_t* __
                 unpack8(*reinterpret_cast<const u32x4*>(act + row * hidden + c), x[r]);
                 if (FROM_PRE) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) x[r][k] = swish_bf16(x[r][k]);
+                    for (int k = 0; k < 8; k++) x[r][k] = swish_fast(x[r][k]);
                 }
             }
 #pragma unroll
