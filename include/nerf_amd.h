@@ -107,7 +107,8 @@ int nerf_weight_gradient_static(const float* d_err, int rows_out, const float* d
 int nerf_convert_bf16(const float* d_src, int rows, int cols, int ld_src, unsigned short* d_dst, int ld_dst,
                       int transpose);
 /* C[M][N] = A[M][K] B[N][K]^T, K-contiguous operands; K a multiple of 64, N, lda, ldb and ldc of 8; all pointers 16-byte aligned.
- * epilogue 0: C = product; 1: C = pre-activation (may be NULL), C2 = swish(C); 2: C = product .* swish'(AUX) */
+ * epilogue 0: C = product; 1: C = pre-activation (may be NULL), C2 = swish(C); 2: C = product .* swish'(AUX);
+ * 5: C = swish'(p), C2 = swish(p) with p the product rounded to bf16; 6: C = product .* AUX */
 int nerf_gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, unsigned short* C, int ldc,
                       int M, int N, int K, int epilogue, unsigned short* C2, const unsigned short* AUX);
 /* dW[rows_out][cols] (+)= Err[batch][rows_out]^T Act[batch][cols], fp32 result (rows_out, ld_err, ld_act
@@ -286,8 +287,8 @@ const float* nerf_trainer_buffer(NerfTrainer* tr, int which);
 /* Floats between consecutive rows of buffer 0 (the encoding): the encoding width rounded up to a
  * multiple of 32 (150 -> 160); the tail of every row is zero. */
 int nerf_trainer_encoding_pitch(const NerfTrainer* tr);
-/* bf16 precision only: 16-bit buffers of the last step, [N][...]: 0 encoding [pitch], 1 layer-1
- * pre-activation (after the backward pass: its error), 2 layer-1 activation, 3 first MLP's output
+/* bf16 precision only: 16-bit buffers of the last step, [N][...]: 0 encoding [pitch], 1 swish' of the layer-1
+ * pre-activation (after the backward pass: that layer's error), 2 layer-1 activation, 3 first MLP's output
  * (after backward: its gradient), 4 layer-3 pre-activation, 5 the error entering layer 3 (written by the
  * backward pass; the layer-3 activation itself is never stored, its readers form it from buffer 4) */
 const unsigned short* nerf_trainer_buffer_bf16(NerfTrainer* tr, int which);

@@ -60,6 +60,10 @@ enum GemmEpilogue {
     EPI_DSWISH_MUL = 2,   // C[m][n] = acc * swish'(AUX[m][n])
     EPI_SPLITK = 3,       // slab[split][m][n] = partial acc   (reduced by reduce_slabs)
     EPI_SWISH_HEAD = 4,   // bf16 products only: C[m][n] = acc and, per 64 columns, the 4-wide output layer's partial sums
+    // bf16 products only: the derivative leaves the forward pass, where the sigmoid is in registers anyway, and
+    // the backward product multiplies by it -- for a hidden layer whose pre-activation has no other reader
+    EPI_SWISH_DSWISH = 5, // C[m][n] = swish'(p), C2[m][n] = swish(p), p = the product rounded to bf16 (never stored)
+    EPI_MUL = 6,          // C[m][n] = acc * AUX[m][n]
 };
 
 struct GemmArgs {
@@ -131,9 +135,10 @@ typedef unsigned short bf16_t;  // storage type of a bf16 value
 struct GemmBf16Args {
     const bf16_t* A;    // [M][lda], k-contiguous rows (points)
     const bf16_t* B;    // [N][ldb], k-contiguous rows (output features)
-    bf16_t* C;          // [M][ldc]: product (EPI_STORE, EPI_DSWISH_MUL) or pre-activation (EPI_SWISH; may be null)
-    bf16_t* C2;         // EPI_SWISH: swish of the rounded pre-activation
-    const bf16_t* AUX;  // EPI_DSWISH_MUL: pre-activation [M][ldc]
+    bf16_t* C;          // [M][ldc]: product (EPI_STORE, EPI_DSWISH_MUL, EPI_MUL), pre-activation (EPI_SWISH; may be
+                        // null) or swish' of the rounded pre-activation (EPI_SWISH_DSWISH)
+    bf16_t* C2;         // EPI_SWISH, EPI_SWISH_DSWISH: swish of the rounded pre-activation
+    const bf16_t* AUX;  // [M][ldc]: pre-activation (EPI_DSWISH_MUL) or the factor itself (EPI_MUL)
     int M, N, K;        // K a multiple of 64, N a multiple of 8
     int lda, ldb, ldc;  // multiples of 8 (rows move in 16-byte pieces)
     int epilogue;

@@ -123,10 +123,10 @@ __device__ __forceinline__ NtRows nt_rows(const GemmBf16Args& p, int m0, int pan
     const int rows_here = (p.M - m0) < panel_rows ? (p.M - m0) : panel_rows;
     const unsigned panel_bytes = (unsigned)(rows_here * p.ldc) * 2u;
     r.rC = __builtin_amdgcn_make_buffer_rsrc((void*)(p.C + (size_t)m0 * p.ldc), 0, p.C ? panel_bytes : 0u, 0x00020000);
-    r.rC2 = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == EPI_SWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes,
-                                              0x00020000);
-    r.rAUX = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == EPI_DSWISH_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0,
-                                               panel_bytes, 0x00020000);
+    r.rC2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((EPI == EPI_SWISH || EPI == EPI_SWISH_DSWISH ? p.C2 : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
+    r.rAUX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((EPI == EPI_DSWISH_MUL || EPI == EPI_MUL ? p.AUX : p.C) + (size_t)m0 * p.ldc), 0, panel_bytes, 0x00020000);
     // row-wise view: lane = (row within a group of 8, 16-byte piece of the line).  The two 8-byte chunks
     // 2j and 2j+1 of a row share one 16-byte slot under the XOR swizzle (it only permutes them inside
     // the slot when the row number is odd), so a row goes to or from memory in eight 16-byte pieces.
@@ -155,8 +155,18 @@ __device__ __forceinline__ void nt_aux_to_stage(const NtRows& r, u32x2* stage, i
     }
 }
 
-// stage -> global rows (and, for the swish epilogue, the activation of the ROUNDED pre-activation:
-// what the backward pass will recompute from)
+// activation and derivative of one (rounded) pre-activation from one sigmoid: swish' = sg (1 + x (1 - sg))
+// = sg + swish (1 - sg)
+__device__ __forceinline__ void swish_and_derivative(float x, float& act, float& der) {
+#pragma clang fp contract(fast)
+    const float sg = sigmoid_fast(x);
+    act = x * sg;
+    der = sg + act * (1.0f - sg);
+}
+
+// stage -> global rows (and, for the swish epilogues, the activation of the ROUNDED pre-activation:
+// what the backward pass will recompute from -- or, EPI_SWISH_DSWISH, its derivative in place of the
+// pre-activation itself, so that the backward pass recomputes nothing)
 template <int ROWS, int EPI>
 __device__ __forceinline__ void nt_stage_to_global(const NtRows& r, const u32x2* stage, int lane) {
     const u32x4* stage16 = reinterpret_cast<const u32x4*>(stage);
@@ -168,6 +178,20 @@ __device__ __forceinline__ void nt_stage_to_global(const NtRows& r, const u32x2*
         const u32x4 raw = stage16[row * 8 + (c16 ^ ((row & 15) >> 1))];
         const u32x4 sw = {raw[2], raw[3], raw[0], raw[1]};
         const u32x4 out = (row & 1) ? sw : raw;
+        if (EPI == EPI_SWISH_DSWISH) {
+            u32x4 act, der;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float a0, a1, d0, d1;
+                swish_and_derivative(bf16_lo(out[e]), a0, d0);
+                swish_and_derivative(bf16_hi(out[e]), a1, d1);
+                act[e] = pack_bf16(a0, a1);
+                der[e] = pack_bf16(d0, d1);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(der, r.rC, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(act, r.rC2, voff, 0, 0);
+            continue;
+        }
         __builtin_amdgcn_raw_buffer_store_b128(out, r.rC, voff, 0, 0);
         if (EPI == EPI_SWISH) {
             u32x4 act;
@@ -228,7 +252,7 @@ __device__ __forceinline__ void nt_stage_to_global_head(const NtRows& r, const u
 }
 
 // four consecutive features of one point: accumulators -> (scaled by swish' of the staged
-// pre-activation) -> bf16 -> the point's row in the stage
+// pre-activation, or by the staged factor itself) -> bf16 -> the point's row in the stage
 template <int EPI>
 __device__ __forceinline__ void nt_put4(u32x2* stage, int row, int c, float v0, float v1, float v2, float v3) {
     u32x2* slot = stage + row * 16 + (c ^ (row & 15));
@@ -236,6 +260,11 @@ __device__ __forceinline__ void nt_put4(u32x2* stage, int row, int c, float v0, 
         const u32x2 a = *slot;
         v0 *= dswish_f(bf16_lo(a[0])); v1 *= dswish_f(bf16_hi(a[0]));
         v2 *= dswish_f(bf16_lo(a[1])); v3 *= dswish_f(bf16_hi(a[1]));
+    }
+    if (EPI == EPI_MUL) {
+        const u32x2 a = *slot;
+        v0 *= bf16_lo(a[0]); v1 *= bf16_hi(a[0]);
+        v2 *= bf16_lo(a[1]); v3 *= bf16_hi(a[1]);
     }
     const u32x2 out = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
     *slot = out;
@@ -248,7 +277,7 @@ __device__ __forceinline__ void nt_store_body(const GemmBf16Args& p, f32x16 (&ac
     constexpr int BM_ = WM * MI * 32, ROWS = MI * 32;
     const NtRows r = nt_rows<EPI>(p, m0, BM_, wm * ROWS, n0 + wn * 64, lane);
     u32x2* stage = reinterpret_cast<u32x2*>(lds_base) + wave * (ROWS * 16);
-    if (EPI == EPI_DSWISH_MUL) nt_aux_to_stage<ROWS>(r, stage, lane);
+    if (EPI == EPI_DSWISH_MUL || EPI == EPI_MUL) nt_aux_to_stage<ROWS>(r, stage, lane);
 #pragma unroll
     for (int mi = 0; mi < MI; mi++) {
         const int row = mi * 32 + (lane & 31);
@@ -270,6 +299,9 @@ __device__ __forceinline__ void nt_store_tile(const GemmBf16Args& p, f32x16 (&ac
     if (p.epilogue == EPI_SWISH) nt_store_body<WM, WN, MI, NI, EPI_SWISH>(p, acc, lds_base, m0, n0, wave, wm, wn, lane);
     else if (p.epilogue == EPI_DSWISH_MUL)
         nt_store_body<WM, WN, MI, NI, EPI_DSWISH_MUL>(p, acc, lds_base, m0, n0, wave, wm, wn, lane);
+    else if (p.epilogue == EPI_SWISH_DSWISH)
+        nt_store_body<WM, WN, MI, NI, EPI_SWISH_DSWISH>(p, acc, lds_base, m0, n0, wave, wm, wn, lane);
+    else if (p.epilogue == EPI_MUL) nt_store_body<WM, WN, MI, NI, EPI_MUL>(p, acc, lds_base, m0, n0, wave, wm, wn, lane);
     else nt_store_body<WM, WN, MI, NI, EPI_STORE>(p, acc, lds_base, m0, n0, wave, wm, wn, lane);
 }
 
@@ -473,11 +505,11 @@ __device__ __forceinline__ void nt8_slice(char* lds, const Nt8Tile& cur, const N
 // stores per wavefront in the epilogue of one tile: 4 passes of 4 rows-of-lines, twice that when the
 // activation (or the output layer's partial sums) is written beside the pre-activation
 template <int EPI>
-constexpr int nt8_stores() { return (EPI == EPI_SWISH || EPI == EPI_SWISH_HEAD) ? 32 : 16; }
+constexpr int nt8_stores() { return (EPI == EPI_SWISH || EPI == EPI_SWISH_HEAD || EPI == EPI_SWISH_DSWISH) ? 32 : 16; }
 
 // A finished tile leaves through the wavefront's own 4 KB of LDS beside the ring, 32 points at a time
 // (the ring keeps running underneath: the next tile's first slices are landing meanwhile).  The
-// pre-activation rows of the swish' epilogue are fetched one pass ahead, before the stores of the pass
+// pre-activation rows of the swish' epilogue (the factors of EPI_MUL) are fetched one pass ahead, before the stores of the pass
 // in hand: waiting for a load also waits for everything issued before it, and that way a pass never
 // waits for its predecessor's stores.
 template <int EPI>
@@ -501,7 +533,8 @@ __device__ __forceinline__ void nt8_store(const GemmBf16Args& p, f32x4acc (&acc)
             aux[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r.rAUX, voff, 0, 0));
         }
     };
-    if (EPI == EPI_DSWISH_MUL) fetch_aux(0);
+    constexpr bool HAS_AUX = EPI == EPI_DSWISH_MUL || EPI == EPI_MUL;
+    if (HAS_AUX) fetch_aux(0);
     float hw[4][8];
     if (EPI == EPI_SWISH_HEAD) {  // the output layer's weights of this lane's 8 columns, rounded as the matrix cores would read them
         const int ncol = n0 + wn * 64 + c16 * 8;
@@ -520,7 +553,7 @@ __device__ __forceinline__ void nt8_store(const GemmBf16Args& p, f32x4acc (&acc)
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        if (EPI == EPI_DSWISH_MUL) {
+        if (HAS_AUX) {
 #pragma unroll
             for (int it = 0; it < 4; it++) {
                 const int row = it * 8 + rsub;
@@ -833,7 +866,8 @@ int gemm_bf16_nt(const GemmBf16Args& g) {
     if (g.lda < g.K || g.ldb < g.K || g.ldc < g.N) return NERF_ERR_ARG;
     if (!aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C) || !aligned16(g.C2) || !aligned16(g.AUX))
         return NERF_ERR_ARG;
-    if (g.epilogue != EPI_STORE && g.epilogue != EPI_SWISH && g.epilogue != EPI_DSWISH_MUL && g.epilogue != EPI_SWISH_HEAD)
+    if (g.epilogue != EPI_STORE && g.epilogue != EPI_SWISH && g.epilogue != EPI_DSWISH_MUL && g.epilogue != EPI_SWISH_HEAD &&
+        g.epilogue != EPI_SWISH_DSWISH && g.epilogue != EPI_MUL)
         return NERF_ERR_ARG;
     if (g.epilogue == EPI_SWISH_HEAD &&
         (!gemm_bf16_nt_head_supported(g.M, g.N, g.K) || !g.C || !g.head_w || !g.head_partial || g.head_ld < g.N ||
@@ -861,6 +895,8 @@ int gemm_bf16_nt(const GemmBf16Args& g) {
         if (g.epilogue == EPI_SWISH) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_SWISH>, gr, bl, 0, stream(), ka);
         else if (g.epilogue == EPI_SWISH_HEAD) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_SWISH_HEAD>, gr, bl, 0, stream(), ka);
         else if (g.epilogue == EPI_DSWISH_MUL) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_DSWISH_MUL>, gr, bl, 0, stream(), ka);
+        else if (g.epilogue == EPI_SWISH_DSWISH) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_SWISH_DSWISH>, gr, bl, 0, stream(), ka);
+        else if (g.epilogue == EPI_MUL) hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_MUL>, gr, bl, 0, stream(), ka);
         else hipLaunchKernelGGL(gemm_bf16_nt8_kernel<EPI_STORE>, gr, bl, 0, stream(), ka);
     } else if (big)
         hipLaunchKernelGGL((gemm_bf16_nt_kernel<2, 4, 4, 2>), dim3((unsigned)grid), dim3(512), 0, stream(), ka);
@@ -939,8 +975,9 @@ extern "C" int nerf_gemm_bf16_nt(const unsigned short* A, int lda, const unsigne
                                  const unsigned short* AUX) {
     using namespace nerf;
     if (!A || !B || (!C && epilogue != EPI_SWISH)) return NERF_ERR_ARG;
-    if (epilogue == EPI_SWISH && !C2) return NERF_ERR_ARG;
-    if (epilogue == EPI_DSWISH_MUL && !AUX) return NERF_ERR_ARG;
+    if ((epilogue == EPI_SWISH || epilogue == EPI_SWISH_DSWISH) && !C2) return NERF_ERR_ARG;
+    if ((epilogue == EPI_DSWISH_MUL || epilogue == EPI_MUL) && !AUX) return NERF_ERR_ARG;
+    if (epilogue == EPI_SWISH_HEAD) return NERF_ERR_ARG;  // needs the output layer's weights: the trainer's own call
     GemmBf16Args g = {};
     g.A = A; g.B = B; g.C = C; g.C2 = C2; g.AUX = AUX;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.epilogue = epilogue;

@@ -538,7 +538,7 @@ const unsigned short* nerf_trainer_buffer_bf16(NerfTrainer* tr, int which) {
     if (!tr || !tr->bf) return nullptr;
     switch (which) {
         case 0: return tr->bf->enc;
-        case 1: return tr->bf->pre1;
+        case 1: return tr->bf->ds1;
         case 2: return tr->bf->act1;
         case 3: return tr->bf->y1;
         case 4: return tr->bf->pre2;

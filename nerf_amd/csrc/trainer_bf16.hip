@@ -4,7 +4,11 @@
 // storage type of every activation and of the weights as the matrix cores read them:
 //
 //   enc   = bf16(encoding)                          [N][192]  (150 used, zero tail)
-//   pre1  = bf16(enc W1a^T), act1 = bf16(swish(pre1))
+//   pre1  = bf16(enc W1a^T) (never stored), act1 = bf16(swish(pre1)), ds1 = bf16(swish'(pre1)): the first
+//                                                     hidden layer's pre-activation has one reader, the
+//                                                     backward pass's swish', so the derivative is stored in
+//                                                     its place -- formed where the sigmoid is in registers
+//                                                     anyway, and the backward product only multiplies
 //   y1    = bf16(act1 W2a^T)
 //   pre2  = bf16(y1 W1b^T)                           (act2 = swish(pre2) is never stored and never rounded:
 //                                                     no matrix instruction reads it.  The output layer's
@@ -15,9 +19,9 @@
 //   raw   = act2 bf16(W2b)^T                         fp32 [N][4] -> compositing, loss, its gradient (fp32)
 //   eh2   = bf16((draw bf16(W2b)) .* swish'(pre2));  dW2b += draw^T act2
 //   dW1b += eh2^T y1;   dy1 = bf16(eh2 W1b);   dW2a += dy1^T act1
-//   eh1   = bf16((dy1 W2a) .* swish'(pre1));    dW1a += eh1^T enc
+//   eh1   = bf16((dy1 W2a) .* ds1);    dW1a += eh1^T enc
 //
-// Buffers are reused once dead (dy1 over y1, eh1 over pre1).  Weight gradients are
+// Buffers are reused once dead (dy1 over y1, eh1 over ds1).  Weight gradients are
 // fp32 sums written into the trainer's gradient arena, exactly where the fp32 step leaves them.
 #include "mlp_internal.hpp"
 #include "trainer_bf16.hpp"
@@ -241,7 +245,7 @@ Bf16Step* bf16_step_create(int pe_dim, int hidden, int inter, int out_dim, long 
     };
     const size_t N = (size_t)points;
     alloc16(&st->enc, N * st->pe_ld);
-    alloc16(&st->pre1, N * hidden); alloc16(&st->act1, N * hidden);
+    alloc16(&st->ds1, N * hidden); alloc16(&st->act1, N * hidden);
     alloc16(&st->y1, N * inter);
     alloc16(&st->pre2, N * hidden); alloc16(&st->eh2, N * hidden);
     alloc16(&st->w1a, (size_t)hidden * st->pe_ld);
@@ -270,7 +274,7 @@ Bf16Step* bf16_step_create(int pe_dim, int hidden, int inter, int out_dim, long 
 
 void bf16_step_destroy(Bf16Step* st) {
     if (!st) return;
-    hipFree(st->enc); hipFree(st->pre1); hipFree(st->act1); hipFree(st->y1); hipFree(st->pre2); hipFree(st->eh2);
+    hipFree(st->enc); hipFree(st->ds1); hipFree(st->act1); hipFree(st->y1); hipFree(st->pre2); hipFree(st->eh2);
     hipFree(st->w1a); hipFree(st->w2a); hipFree(st->w2aT); hipFree(st->w1b); hipFree(st->w1bT);
     hipFree(st->raw); hipFree(st->draw); hipFree(st->workspace); hipFree(st->head_partial);
     free(st);
@@ -298,7 +302,7 @@ static int nt(const bf16_t* A, int lda, const bf16_t* B, int ldb, bf16_t* C, bf1
 int bf16_step_forward(Bf16Step* st, const float* W2b) {
     const long N = st->points;
     const int H = st->hidden, M = st->inter, O = st->out_dim;
-    int rc = nt(st->enc, st->pe_ld, st->w1a, st->pe_ld, st->pre1, st->act1, nullptr, H, N, H, st->pe_ld, EPI_SWISH, K_GEMM_FWD);
+    int rc = nt(st->enc, st->pe_ld, st->w1a, st->pe_ld, st->ds1, st->act1, nullptr, H, N, H, st->pe_ld, EPI_SWISH_DSWISH, K_GEMM_FWD);
     if (rc == NERF_OK) rc = nt(st->act1, H, st->w2a, H, st->y1, nullptr, nullptr, M, N, M, H, EPI_STORE, K_GEMM_FWD);
     if (rc != NERF_OK) return rc;
     if (st->head_partial && (reinterpret_cast<uintptr_t>(W2b) & 15) == 0) {
@@ -354,8 +358,8 @@ int bf16_step_backward(Bf16Step* st, const float* W2b, float* dW1a, float* dW2a,
     bf16_t* dy1 = st->y1;  // y1 is dead once dW1b is formed
     if (rc == NERF_OK) rc = nt(eh2, H, st->w1bT, H, dy1, nullptr, nullptr, M, N, M, H, EPI_STORE, K_GEMM_DGRAD);
     if (rc == NERF_OK) rc = weight_gradient_bf16(dy1, M, M, st->act1, H, H, N, dW2a, st->workspace, accumulate);
-    bf16_t* eh1 = st->pre1;  // in place: every element of pre1 is read by the lane that overwrites it
-    if (rc == NERF_OK) rc = nt(dy1, M, st->w2aT, M, eh1, nullptr, st->pre1, H, N, H, M, EPI_DSWISH_MUL, K_GEMM_DGRAD);
+    bf16_t* eh1 = st->ds1;  // in place: every element of ds1 is read by the lane that overwrites it
+    if (rc == NERF_OK) rc = nt(dy1, M, st->w2aT, M, eh1, nullptr, st->ds1, H, N, H, M, EPI_MUL, K_GEMM_DGRAD);
     if (rc == NERF_OK) rc = weight_gradient_bf16(eh1, H, H, st->enc, st->pe_dim, st->pe_ld, N, dW1a, st->workspace, accumulate);
     return rc;
 }

@@ -10,7 +10,7 @@ struct Bf16Step {
     long points;
     // activations (bf16 unless noted), [points][...]
     bf16_t* enc;    // [pe_ld]: encoding, zero tail
-    bf16_t* pre1;   // [hidden]; reused for eh1
+    bf16_t* ds1;    // [hidden]: swish' of the first hidden layer's (rounded) pre-activation; reused for eh1
     bf16_t* act1;   // [hidden]
     bf16_t* y1;     // [inter]; reused for dy1
     bf16_t* pre2;   // [hidden]

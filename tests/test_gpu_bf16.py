@@ -59,7 +59,7 @@ def test_convert_rounds_to_nearest_even_and_transposes(gpu):
                                    # several tiles per workgroup, ragged in M and N; a grid of 258 tiles (two
                                    # workgroups get a second tile); one tile per workgroup
                                    (70000, 520, 512), (40000, 1032, 1024), (33000, 512, 512), (32768, 512, 1024)])
-@pytest.mark.parametrize("epilogue", [0, 1, 2])
+@pytest.mark.parametrize("epilogue", [0, 1, 2, 5, 6])
 def test_nt_product(gpu, M, N, K, epilogue):
     from nerf_amd._lib import lib
     from nerf_amd.api import DeviceArray
@@ -75,8 +75,26 @@ def test_nt_product(gpu, M, N, K, epilogue):
     assert lib.nerf_gemm_bf16_nt(d_A.ptr, K, d_B.ptr, K, d_C.ptr, N, M, N, K, epilogue, d_C2.ptr, d_aux.ptr) == 0
     C = from_bf16_bits(d_C.numpy()).astype(np.float64)
     scale = np.abs(ref).max()
+    if epilogue == 5:
+        # C = swish'(p), C2 = swish(p) of the product rounded to bf16, which is not stored: the device's p is
+        # numpy's or (fp32 accumulation order, rarely) one of its two bf16 neighbours
+        p_bits = to_bf16_bits(ref).astype(np.int32)
+        act = from_bf16_bits(d_C2.numpy()).astype(np.float64)
+        ok_d = np.zeros(C.shape, bool)
+        ok_a = np.zeros(C.shape, bool)
+        for step in (0, 1, -1):
+            q = from_bf16_bits((p_bits + step).astype(np.uint16)).astype(np.float64)
+            ok_d |= np.abs(C - dswish(q)) <= 0.51 * BF16_EPS * np.abs(dswish(q)) + 1e-6
+            ok_a |= np.abs(act - swish(q)) <= 0.51 * BF16_EPS * np.abs(swish(q)) + 1e-6
+        assert ok_d.all() and ok_a.all()
+        # the neighbours are the exception: nearly every element comes from numpy's own rounding
+        q = from_bf16_bits(p_bits.astype(np.uint16)).astype(np.float64)
+        assert np.mean(np.abs(C - dswish(q)) <= 0.51 * BF16_EPS * np.abs(dswish(q)) + 1e-6) > 0.99
+        return
     if epilogue == 2:
         ref = ref * dswish(from_bf16_bits(aux).astype(np.float64))
+    if epilogue == 6:
+        ref = ref * from_bf16_bits(aux).astype(np.float64)
     # one bf16 rounding of the result (+ fp32 accumulation, far smaller)
     assert np.all(np.abs(C - ref) <= 0.51 * BF16_EPS * np.abs(ref) + 1e-5 * scale)
     if epilogue == 1:
@@ -212,7 +230,8 @@ def test_bf16_step_stage_by_stage(gpu, oracle, R, S, hidden, inter):
     def close(a, b, tol):
         assert np.abs(a - b).max() <= tol * np.abs(b).max(), (np.abs(a - b).max(), np.abs(b).max())
 
-    # forward: layer 1 (pre1 is overwritten by the backward pass; act1 survives)
+    # forward: layer 1 (its pre-activation is never stored: act1 and, until the backward pass overwrites it
+    # with the layer's error, swish'(pre1) are)
     pre1 = bf(enc @ W1a.T)
     assert within_bf16_ulps(act1_bits, swish(pre1), 1.6)          # one flip in pre1 moves act1 by about an ulp
     y1 = bf(act1 @ W2a.T)                                          # from the device's act1

@@ -36,6 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=2097152)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--old-epilogues", action="store_true")
     a = ap.parse_args()
     assert lib.nerf_set_device(0) == 0
     rng = np.random.default_rng(0)
@@ -61,14 +62,14 @@ def main():
         f = lambda: lib.nerf_gemm_bf16_nt(A.ptr, lda, B.ptr, lda, C.ptr if C else 0, ldc, N, n, k, epi,
                                           C2.ptr if C2 else 0, AUX.ptr if AUX else 0)
         assert f() == 0, name
-        byt = 2.0 * N * (k + n * (1 + (epi == 1) + (epi == 2)))
+        byt = 2.0 * N * (k + n * (1 + (epi in (1, 5)) + (epi in (2, 6))))
         report(name, timeit(f, a.reps), 2.0 * N * n * k, byt)
 
-    nt("forward  enc -> pre1, act1   (K 192, swish)", bufs["enc"], PE, w["w1a"], bufs["h3"], bufs["h1"], None, H, H, PE, 1)
+    nt("forward  enc -> swish', act1 (K 192, swish)", bufs["enc"], PE, w["w1a"], bufs["h3"], bufs["h1"], None, H, H, PE, 5)
     nt("forward  act1 -> y1          (K 1024)", bufs["h1"], H, w["w2a"], bufs["m2"], None, None, M, M, H, 0)
     nt("forward  y1 -> pre2          (K 512)", bufs["m"], M, w["w1b"], bufs["h3"], None, None, H, H, M, 0)
     nt("backward eh2 -> dy1          (K 1024)", bufs["h2"], H, w["w1bT"], bufs["m2"], None, None, M, M, H, 0)
-    nt("backward dy1 -> eh1          (K 512, swish')", bufs["m"], M, w["w2aT"], bufs["h3"], None, bufs["h1"], H, H, M, 2)
+    nt("backward dy1 -> eh1          (K 512, .* aux)", bufs["m"], M, w["w2aT"], bufs["h3"], None, bufs["h1"], H, H, M, 6)
     for name, err, ro, act, cols, ld in (("weight gradient eh2^T y1   (1024 x 512)", "h2", H, "m", M, M),
                                          ("weight gradient dy1^T act1 (512 x 1024)", "m", M, "h1", H, H),
                                          ("weight gradient eh1^T enc  (1024 x 150)", "h1", H, "enc", 150, PE)):
@@ -78,6 +79,9 @@ def main():
         assert f() == 0, name
         report(name, timeit(f, a.reps), 2.0 * N * ro * cols, 2.0 * N * (ro + ld))
     print(f"{'all eight':44s} {total_ms:7.3f} ms  {total_flop / total_ms / 1e9:7.0f} TFLOP/s  {total_bytes / total_ms / 1e6:6.0f} GB/s")
+    if a.old_epilogues:  # the same two products as they were: the pre-activation stored, its swish' formed in the backward product
+        nt("forward  enc -> pre1, act1   (K 192, swish)", bufs["enc"], PE, w["w1a"], bufs["h3"], bufs["h1"], None, H, H, PE, 1)
+        nt("backward dy1 -> eh1          (K 512, swish')", bufs["m"], M, w["w2aT"], bufs["h3"], None, bufs["h1"], H, H, M, 2)
 
 
 if __name__ == "__main__":
