@@ -144,7 +144,7 @@ struct GemmBf16Args {
     int epilogue;
     // EPI_SWISH_HEAD: head_w [4][head_ld] fp32 (rounded to bf16 as it is read), head_partial
     // [ceil(N / 64)][M][4] fp32: block b, row m holds sum over columns 64 b .. 64 b + 63 of
-    // swish(C[m][n]) * bf16(head_w[o][n]) for o = 0..3 (fp32 arithmetic on the rounded C)
+    // bf16(swish(C[m][n])) * bf16(head_w[o][n]) for o = 0..3 (matrix instructions, fp32 accumulation)
     const float* head_w;
     int head_ld;
     float* head_partial;

@@ -202,59 +202,10 @@ __device__ __forceinline__ void nt_stage_to_global(const NtRows& r, const u32x2*
     }
 }
 
-// lane l receives src from lane l - N of its row of 16 (zero from outside the row)
-template <int N>
-__device__ __forceinline__ float row_shr_or_zero(float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x110 + N, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ float quad_perm(float src) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), CTRL, 0xf, 0xf, true));
-}
-
-// stage -> global rows of the pre-activation, and the 4-wide output layer's share of these 64 columns:
-// the activation (swish of the ROUNDED pre-activation, in fp32: no matrix instruction reads it) never
-// leaves the registers; hw[o][k] is the output layer's weight for this lane's column k.  The eight
-// lanes of a row add up in a fixed order; lane 7 of each eight stores the row's four sums.  Multiply-adds
-// may fuse in here (they may not in the fp32 kernels that share this build's flags).
-template <int ROWS>
-__device__ __forceinline__ void nt_stage_to_global_head(const NtRows& r, const u32x2* stage, int lane, const float (&hw)[4][8]) {
-#pragma clang fp contract(fast)
-    const u32x4* stage16 = reinterpret_cast<const u32x4*>(stage);
-    const int rsub = lane >> 3, c16 = lane & 7;
-#pragma unroll
-    for (int it = 0; it < ROWS / 8; it++) {
-        const int row = it * 8 + rsub;
-        const unsigned voff = r.col_off == OOR ? OOR : (unsigned)(r.row0 + row) * r.row_bytes + r.col_off;
-        const u32x4 raw = stage16[row * 8 + (c16 ^ ((row & 15) >> 1))];
-        const u32x4 sw = {raw[2], raw[3], raw[0], raw[1]};
-        const u32x4 out = (row & 1) ? sw : raw;
-        __builtin_amdgcn_raw_buffer_store_b128(out, r.rC, voff, 0, 0);
-        float a[8];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            a[2 * e] = swish_f(bf16_lo(out[e]));
-            a[2 * e + 1] = swish_f(bf16_hi(out[e]));
-        }
-        f32x4 s;
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            float t = a[0] * hw[o][0];
-#pragma unroll
-            for (int k = 1; k < 8; k++) t += a[k] * hw[o][k];
-            t += quad_perm<0xb1>(t);      // lanes l ^ 1
-            t += quad_perm<0x4e>(t);      // lanes l ^ 2
-            t += row_shr_or_zero<4>(t);   // lanes 4..7 of each eight now hold the row's sum
-            s[o] = t;
-        }
-        if (c16 == 7) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), r.rP, (unsigned)(r.row0 + row) * 16u, 0, 0);
-    }
-}
-
 // four consecutive features of one point: accumulators -> (scaled by swish' of the staged
 // pre-activation, or by the staged factor itself) -> bf16 -> the point's row in the stage
 template <int EPI>
-__device__ __forceinline__ void nt_put4(u32x2* stage, int row, int c, float v0, float v1, float v2, float v3) {
+__device__ __forceinline__ u32x2 nt_put4(u32x2* stage, int row, int c, float v0, float v1, float v2, float v3) {
     u32x2* slot = stage + row * 16 + (c ^ (row & 15));
     if (EPI == EPI_DSWISH_MUL) {
         const u32x2 a = *slot;
@@ -268,6 +219,7 @@ __device__ __forceinline__ void nt_put4(u32x2* stage, int row, int c, float v0, 
     }
     const u32x2 out = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
     *slot = out;
+    return out;
 }
 
 template <int WM, int WN, int MI, int NI, int EPI>
@@ -505,7 +457,7 @@ __device__ __forceinline__ void nt8_slice(char* lds, const Nt8Tile& cur, const N
 // stores per wavefront in the epilogue of one tile: 4 passes of 4 rows-of-lines, twice that when the
 // activation (or the output layer's partial sums) is written beside the pre-activation
 template <int EPI>
-constexpr int nt8_stores() { return (EPI == EPI_SWISH || EPI == EPI_SWISH_HEAD || EPI == EPI_SWISH_DSWISH) ? 32 : 16; }
+constexpr int nt8_stores() { return (EPI == EPI_SWISH || EPI == EPI_SWISH_DSWISH) ? 32 : EPI == EPI_SWISH_HEAD ? 24 : 16; }
 
 // A finished tile leaves through the wavefront's own 4 KB of LDS beside the ring, 32 points at a time
 // (the ring keeps running underneath: the next tile's first slices are landing meanwhile).  The
@@ -535,21 +487,31 @@ __device__ __forceinline__ void nt8_store(const GemmBf16Args& p, f32x4acc (&acc)
     };
     constexpr bool HAS_AUX = EPI == EPI_DSWISH_MUL || EPI == EPI_MUL;
     if (HAS_AUX) fetch_aux(0);
-    float hw[4][8];
-    if (EPI == EPI_SWISH_HEAD) {  // the output layer's weights of this lane's 8 columns, rounded as the matrix cores would read them
-        const int ncol = n0 + wn * 64 + c16 * 8;
+    // EPI_SWISH_HEAD: the output layer's weights for this wavefront's 64 columns as the row operand of two
+    // matrix instructions (columns 0..31 and 32..63 of the block).  Row i = lane & 15 is output i (rows 4..15
+    // are zero); contraction slots 0..3 / 4..7 of lane group g = lane >> 4 are columns 16 t + 4 g + (0..3) of
+    // the accumulator tiles t = 2 pair, 2 pair + 1 -- the order in which the activation operand is put together
+    // below, straight from the accumulator layout.
+    bf16x8 head_op[2];
+    __amdgpu_buffer_rsrc_t rP;
+    if (EPI == EPI_SWISH_HEAD) {
+        const int o = lane & 15, g = lane >> 4;
+        const int ncol0 = n0 + wn * 64;
         const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.head_w, 0, (unsigned)(4 * p.head_ld) * 4u, 0x00020000);
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
-            const unsigned woff = ncol + 7 < p.N ? (unsigned)(o * p.head_ld + ncol) * 4u : OOR;
-            const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, woff, 0, 0));
-            const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, woff == OOR ? OOR : woff + 16u, 0, 0));
+        for (int pair = 0; pair < 2; pair++) {
+            u32x4 w;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                hw[o][k] = bf16_lo(pack_bf16(lo[k], 0.f));
-                hw[o][4 + k] = bf16_lo(pack_bf16(hi[k], 0.f));
+            for (int t = 0; t < 2; t++) {
+                const int col = ncol0 + 16 * (2 * pair + t) + 4 * g;
+                const unsigned woff = (o < 4 && col + 3 < p.N) ? (unsigned)(o * p.head_ld + col) * 4u : OOR;
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, woff, 0, 0));
+                w[2 * t] = pack_bf16(v[0], v[1]);
+                w[2 * t + 1] = pack_bf16(v[2], v[3]);
             }
+            head_op[pair] = __builtin_bit_cast(bf16x8, w);
         }
+        rP = r.rP;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -565,15 +527,36 @@ __device__ __forceinline__ void nt8_store(const GemmBf16Args& p, f32x4acc (&acc)
         }
         // accumulator tile (ni, mi): lane l holds point 16 mi + (l & 15), features 16 ni + 4 (l >> 4) + (0..3)
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int h = 0; h < 2; h++) {
+            u32x2 pre[4];
 #pragma unroll
             for (int ni = 0; ni < 4; ni++)
-                nt_put4<EPI>(stage, h * 16 + (lane & 15), ni * 4 + (lane >> 4), acc[ni][2 * q + h][0], acc[ni][2 * q + h][1],
-                             acc[ni][2 * q + h][2], acc[ni][2 * q + h][3]);
+                pre[ni] = nt_put4<EPI>(stage, h * 16 + (lane & 15), ni * 4 + (lane >> 4), acc[ni][2 * q + h][0],
+                                       acc[ni][2 * q + h][1], acc[ni][2 * q + h][2], acc[ni][2 * q + h][3]);
+            if (EPI == EPI_SWISH_HEAD) {
+                // the output layer's share of these 16 points x 64 columns: the activation of the ROUNDED
+                // pre-activation, rounded to bf16 like every other operand of a matrix instruction, never
+                // leaves the registers; sums[i][j] (output i, point j) lands with point j = lane & 15 and
+                // outputs 4 (lane >> 4) + (0..3), so lanes 0..15 hold the four sums of their point
+                f32x4acc sums = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int pair = 0; pair < 2; pair++) {
+                    u32x4 a;
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const u32x2 x = pre[2 * pair + t];
+                        a[2 * t] = pack_bf16(swish_f(bf16_lo(x[0])), swish_f(bf16_hi(x[0])));
+                        a[2 * t + 1] = pack_bf16(swish_f(bf16_lo(x[1])), swish_f(bf16_hi(x[1])));
+                    }
+                    sums = __builtin_amdgcn_mfma_f32_16x16x32_bf16(head_op[pair], __builtin_bit_cast(bf16x8, a), sums, 0, 0, 0);
+                }
+                const unsigned poff = lane < 16 ? (unsigned)(wm * 128 + q * 32 + h * 16 + lane) * 16u : OOR;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sums), rP, poff, 0, 0);
+            }
+        }
         NtRows rq = r;
         rq.row0 = wm * 128 + q * 32;
-        if (EPI == EPI_SWISH_HEAD) nt_stage_to_global_head<32>(rq, stage, lane, hw);
-        else nt_stage_to_global<32, EPI>(rq, stage, lane);
+        nt_stage_to_global<32, EPI>(rq, stage, lane);
     }
 }
 

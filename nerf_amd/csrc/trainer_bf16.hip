@@ -10,12 +10,11 @@
 //                                                     its place -- formed where the sigmoid is in registers
 //                                                     anyway, and the backward product only multiplies
 //   y1    = bf16(act1 W2a^T)
-//   pre2  = bf16(y1 W1b^T)                           (act2 = swish(pre2) is never stored and never rounded:
-//                                                     no matrix instruction reads it.  The output layer's
-//                                                     forward sums are formed where pre2 is -- in that
-//                                                     product's epilogue for large batches, else by a
-//                                                     kernel that reads pre2 -- and its backward pass
-//                                                     reads pre2 as well)
+//   pre2  = bf16(y1 W1b^T)                           (act2 = bf16(swish(pre2)) is never stored.  The output
+//                                                     layer's forward sums are formed where pre2 is -- by
+//                                                     matrix instructions in that product's epilogue for
+//                                                     large batches, else by a kernel that reads pre2 --
+//                                                     and its backward pass reads pre2 as well)
 //   raw   = act2 bf16(W2b)^T                         fp32 [N][4] -> compositing, loss, its gradient (fp32)
 //   eh2   = bf16((draw bf16(W2b)) .* swish'(pre2));  dW2b += draw^T act2
 //   dW1b += eh2^T y1;   dy1 = bf16(eh2 W1b);   dW2a += dy1^T act1
@@ -60,7 +59,7 @@ __device__ __forceinline__ float swish_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
 }
 
-// raw[n][o] = sum_h act[n][h] * bf16(W2[o][h]), with act = swish(pre) formed here (fp32) when FROM_PRE.
+// raw[n][o] = sum_h act[n][h] * bf16(W2[o][h]), with act = bf16(swish(pre)) formed here when FROM_PRE.
 // A 16-lane group takes HEAD_ROWS points at a time, 8 features per lane and step, so every weight
 // read from LDS is used HEAD_ROWS times.
 constexpr int HEAD_ROWS = 4;
@@ -86,9 +85,9 @@ __global__ __launch_bounds__(256) void head_forward_bf16_kernel(const bf16_t* __
             for (int r = 0; r < HEAD_ROWS; r++) {
                 const long row = row0 + r < rows ? row0 + r : rows - 1;  // clamp: the extra rows are not stored
                 unpack8(*reinterpret_cast<const u32x4*>(act + row * hidden + c), x[r]);
-                if (FROM_PRE) {
+                if (FROM_PRE) {  // rounded like every operand of a matrix instruction: large batches form these sums with them
 #pragma unroll
-                    for (int k = 0; k < 8; k++) x[r][k] = swish_fast(x[r][k]);
+                    for (int k = 0; k < 8; k++) x[r][k] = bf16_round(swish_fast(x[r][k]));
                 }
             }
 #pragma unroll

@@ -236,8 +236,10 @@ def test_bf16_step_stage_by_stage(gpu, oracle, R, S, hidden, inter):
     assert within_bf16_ulps(act1_bits, swish(pre1), 1.6)          # one flip in pre1 moves act1 by about an ulp
     y1 = bf(act1 @ W2a.T)                                          # from the device's act1
     assert within_bf16_ulps(pre2_bits, y1 @ W1b.T, 3.0, atol=3 * BF16_EPS * np.abs(y1 @ W1b.T).max() * 1e-2)
-    act2 = swish(pre2)                                             # from the device's pre2; fp32, never rounded or stored
-    close(raw, act2 @ W2b.T, 2e-5)                                 # fp32 sums of hardware-exp2 sigmoids
+    act2 = swish(pre2)                                             # from the device's pre2; never stored
+    # fp32 sums of bf16 products; the device's hardware-exp2 sigmoid can land an activation on the other side
+    # of a rounding boundary (one bf16 ulp of one term in 1024)
+    close(raw, bf(act2) @ W2b.T, 1e-4)
     # compositing on the device's raw: the fp32 kernels, checked elsewhere; here the loss bookkeeping
     dens, rgb = oracle.activation(raw.astype(np.float32))
     pix, err, loss, guard = oracle.composite_and_loss(dens, rgb, col, R, S)
