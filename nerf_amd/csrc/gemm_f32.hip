@@ -332,65 +332,86 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(const KernelArgs k
 // dst[i] = (accumulate ? dst[i] : 0) + slabs[0][i] + slabs[1][i] + ...  in that order (reproducible).
 // Thread = 4 consecutive elements; the slab loop is unrolled so 8 independent 16-byte loads are in
 // flight per thread (a serial chain of dependent loads ran this HBM-bound sum at 5% of the roof).
-template <bool VEC4>
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, int splits, size_t stride,
-                                                           float* __restrict__ dst, size_t n, int accumulate) {
-    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * (VEC4 ? 4 : 1);
-    if (i >= n) return;
-    if (VEC4) {
-        f32x4 s = accumulate ? *reinterpret_cast<const f32x4*>(dst + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 8 <= splits; k += 8) {
-            f32x4 v[8];
+//
+// Many slabs over few elements (the output layer's gradient: 4 x 512 values in up to 1024 slabs, one per
+// workgroup of its backward kernel) would leave a handful of threads walking a chain of a hundred and more
+// dependent rounds of loads -- at the 4096-ray batch that chain was the whole launch, 86 us.  Such a sum is
+// GROUPED: the slabs are cut into 16 consecutive groups, a workgroup takes 16 four-element columns, thread
+// (group, column) adds its group's slabs in order, and the 16 partial sums of a column are added in order
+// of the groups.  Still a fixed order -- the same bits on every run and from both kernels below -- but not
+// the order of the single chain.
+inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
+
+constexpr int REDUCE_GROUPS = 16;         // partial sums per element of a grouped job
+constexpr int REDUCE_GROUPED_FROM = 128;  // slabs from which a job is grouped
+
+inline bool reduce_vec4(const ReduceJob& q) {
+    return q.n % 4 == 0 && q.stride % 4 == 0 && aligned_to(q.slabs, 16) && aligned_to(q.dst, 16);
+}
+inline bool reduce_grouped(const ReduceJob& q) { return q.splits >= REDUCE_GROUPED_FROM && reduce_vec4(q); }
+inline unsigned reduce_blocks(const ReduceJob& q) {
+    if (reduce_grouped(q)) return (unsigned)((q.n / 4 + 15) / 16);
+    return (unsigned)(((reduce_vec4(q) ? q.n / 4 : q.n) + 255) / 256);
+}
+
+// slabs [k0, k1) of four consecutive elements, added to s in order
+__device__ __forceinline__ f32x4 sum_slabs4(const float* __restrict__ slabs, size_t stride, size_t i, int k0, int k1, f32x4 s) {
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {
+        f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x4*>(slabs + (size_t)(k + u) * stride + i);
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x4*>(slabs + (size_t)(k + u) * stride + i);
 #pragma unroll
-            for (int u = 0; u < 8; u++) s += v[u];
+        for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; k < k1; k++) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * stride + i);
+    return s;
+}
+
+// mode: 0 one element per thread, 1 four per thread, 2 grouped
+__device__ __forceinline__ void reduce_job(const ReduceJob& q, int mode, unsigned block) {
+    __shared__ f32x4 part[REDUCE_GROUPS][16];
+    if (mode == 2) {
+        const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
+        const size_t i = ((size_t)block * 16 + c) * 4;
+        const int per_group = (q.splits + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
+        const int k0 = g * per_group, k1 = min(q.splits, k0 + per_group);
+        if (i < q.n) part[g][c] = sum_slabs4(q.slabs, q.stride, i, k0, k1, f32x4{0.f, 0.f, 0.f, 0.f});
+        __syncthreads();
+        if (g == 0 && i < q.n) {
+            f32x4 s = q.accumulate ? *reinterpret_cast<const f32x4*>(q.dst + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gg = 0; gg < REDUCE_GROUPS; gg++) s += part[gg][c];
+            *reinterpret_cast<f32x4*>(q.dst + i) = s;
         }
-        for (; k < splits; k++) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * stride + i);
-        *reinterpret_cast<f32x4*>(dst + i) = s;
+    } else if (mode == 1) {
+        const size_t i = ((size_t)block * 256 + threadIdx.x) * 4;
+        if (i >= q.n) return;
+        const f32x4 s0 = q.accumulate ? *reinterpret_cast<const f32x4*>(q.dst + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(q.dst + i) = sum_slabs4(q.slabs, q.stride, i, 0, q.splits, s0);
     } else {
-        float s = accumulate ? dst[i] : 0.f;
-        for (int k = 0; k < splits; k++) s += slabs[(size_t)k * stride + i];
-        dst[i] = s;
+        const size_t t = (size_t)block * 256 + threadIdx.x;
+        if (t >= q.n) return;
+        float s = q.accumulate ? q.dst[t] : 0.f;
+        for (int k = 0; k < q.splits; k++) s += q.slabs[(size_t)k * q.stride + t];
+        q.dst[t] = s;
     }
 }
 
-inline bool aligned_to(const void* ptr, size_t a) { return (reinterpret_cast<uintptr_t>(ptr) % a) == 0; }
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const ReduceJob q, int mode) { reduce_job(q, mode, blockIdx.x); }
 
 // up to four slab sums in one launch: workgroup b works on the job whose block range holds b, with
 // the arithmetic of reduce_slabs_kernel (same order, same bits)
 struct ReduceBatch {
     ReduceJob job[ReduceQueue::MAX_JOBS];
     unsigned first_block[ReduceQueue::MAX_JOBS + 1];
-    int vec4[ReduceQueue::MAX_JOBS];
+    int mode[ReduceQueue::MAX_JOBS];
     int count;
 };
 __global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceBatch b) {
     int j = 0;
     while (j + 1 < b.count && blockIdx.x >= b.first_block[j + 1]) j++;
-    const ReduceJob& q = b.job[j];
-    const size_t t = (size_t)(blockIdx.x - b.first_block[j]) * 256 + threadIdx.x;
-    if (b.vec4[j]) {
-        const size_t i = t * 4;
-        if (i >= q.n) return;
-        f32x4 s = q.accumulate ? *reinterpret_cast<const f32x4*>(q.dst + i) : f32x4{0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 8 <= q.splits; k += 8) {
-            f32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x4*>(q.slabs + (size_t)(k + u) * q.stride + i);
-#pragma unroll
-            for (int u = 0; u < 8; u++) s += v[u];
-        }
-        for (; k < q.splits; k++) s += *reinterpret_cast<const f32x4*>(q.slabs + (size_t)k * q.stride + i);
-        *reinterpret_cast<f32x4*>(q.dst + i) = s;
-    } else {
-        if (t >= q.n) return;
-        float s = q.accumulate ? q.dst[t] : 0.f;
-        for (int k = 0; k < q.splits; k++) s += q.slabs[(size_t)k * q.stride + t];
-        q.dst[t] = s;
-    }
+    reduce_job(b.job[j], b.mode[j], blockIdx.x - b.first_block[j]);
 }
 
 // widest vector width (4, 2, 1) the operand allows
@@ -505,13 +526,9 @@ int gemm_f32(const GemmArgs& g) {
 }
 
 void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {
-    const bool vec4 = n % 4 == 0 && stride % 4 == 0 && aligned_to(slabs, 16) && aligned_to(dst, 16);
-    if (vec4)
-        hipLaunchKernelGGL(reduce_slabs_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream(),
-                           slabs, splits, stride, dst, n, accumulate);
-    else
-        hipLaunchKernelGGL(reduce_slabs_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(),
-                           slabs, splits, stride, dst, n, accumulate);
+    const ReduceJob q{slabs, dst, stride, n, splits, accumulate};
+    const int mode = reduce_grouped(q) ? 2 : reduce_vec4(q) ? 1 : 0;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(reduce_blocks(q)), dim3(256), 0, stream(), q, mode);
 }
 
 void ReduceQueue::add(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {
@@ -532,9 +549,9 @@ void ReduceQueue::flush() {
         for (int j = 0; j < count; j++) {
             const ReduceJob& q = jobs[j];
             b.job[j] = q;
-            b.vec4[j] = q.n % 4 == 0 && q.stride % 4 == 0 && aligned_to(q.slabs, 16) && aligned_to(q.dst, 16);
+            b.mode[j] = reduce_grouped(q) ? 2 : reduce_vec4(q) ? 1 : 0;
             b.first_block[j] = blocks;
-            blocks += (unsigned)(((b.vec4[j] ? q.n / 4 : q.n) + 255) / 256);
+            blocks += reduce_blocks(q);
         }
         for (int j = count; j <= MAX_JOBS; j++) b.first_block[j] = blocks;
         hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, stream(), b);
