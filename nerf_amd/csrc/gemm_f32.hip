@@ -144,10 +144,101 @@ template __global__ void gemm_dma_kernel<false, false, 2, 2, 2, 2>(const KernelA
 template __global__ void gemm_dma_kernel<false, false, 4, 1, 1, 5>(const KernelArgs);
 template __global__ void gemm_dma_kernel<true, true, 2, 2, 2, 2, 16>(const KernelArgs);
 template __global__ void gemm_dma_kernel<true, false, 2, 2, 2, 2, 16>(const KernelArgs);
-// 64x64 tiles (one MFMA tile per wavefront) for products too small to fill the chip with 128x128 ones
-template __global__ void gemm_dma_kernel<true, true, 2, 2, 1, 1, 16>(const KernelArgs);
-template __global__ void gemm_dma_kernel<true, false, 2, 2, 1, 1, 16>(const KernelArgs);
-template __global__ void gemm_dma_kernel<false, false, 2, 2, 1, 1, 16>(const KernelArgs);
+
+// 64x64 tiles (one MFMA tile per wavefront) for products too small to fill the chip with 128x128 ones.
+// Such a product has ONE workgroup per CU and one wavefront per SIMD, so nothing covers a wait inside its
+// loop, and with two staged K-tiles the transfer of the next 16-step tile has only the 8 matrix
+// instructions of the current one (0.2 us) to arrive in -- less than a trip to the L2 -- and the first
+// fragment reads of every tile wait out an LDS latency behind the barrier.  Here five tiles are staged
+// (40 KB): a tile is asked for four tiles before it is multiplied, the wait is counted (the two youngest
+// tiles, one transfer per operand and wavefront each, may still be on their way), the barrier is a bare
+// one and guarantees the NEXT tile, so that tile's first fragments are read during the second half of
+// the current tile's matrix instructions and are in registers when the barrier opens.  A tile past the end is
+// fetched again from the last one and never used, which keeps the counts the same to the end.
+// Same contraction order as gemm_dma_kernel: the same bits.
+constexpr int RING = 5, RING_TILE = 128 * 16;  // floats per staged tile pair: [64 x 16] of A, then of B
+
+template <bool A_KC, bool B_KC, int SLOT>
+__device__ __forceinline__ void ring_tile(float (&lds)[RING][RING_TILE], const DmaLoader<A_KC, 64, 256, 16>& da,
+                                          const DmaLoader<B_KC, 64, 256, 16>& db, f32x16& acc, float (&fa)[2][4],
+                                          float (&fb)[2][4], int next, int wave, int wm, int wn, int lane) {
+    constexpr int NEXT = (SLOT + 1) % RING, FREE = (SLOT + 4) % RING;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // this wavefront's pieces of the tile in NEXT have landed
+    __builtin_amdgcn_s_barrier();                       // everybody's have, and everybody is done with slot FREE
+    asm volatile("" ::: "memory");
+    da.issue(lds[FREE], next, wave);
+    db.issue(lds[FREE] + 64 * 16, next, wave);
+    // steps 8..15 of this tile, then (fa[0], fb[0] hold steps 0..7 on entry) the matrix instructions
+    dma_frag<A_KC, 64, 16>(fa[1], lds[SLOT], wm * 32, 1, lane);
+    dma_frag<B_KC, 64, 16>(fb[1], lds[SLOT] + 64 * 16, wn * 32, 1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][j], fb[0][j], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_frag<A_KC, 64, 16>(fa[0], lds[NEXT], wm * 32, 0, lane);
+    dma_frag<B_KC, 64, 16>(fb[0], lds[NEXT] + 64 * 16, wn * 32, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][j], fb[1][j], acc, 0, 0, 0);
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 3) void gemm_dma_ring_kernel(const KernelArgs ka) {
+    __shared__ __attribute__((aligned(16))) float lds[RING][RING_TILE];
+    const GemmArgs& p = ka.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn, split;
+    decode_block(ka, blockIdx.x, tm, tn, split);
+    const int m0 = tm * 64, n0 = tn * 64;
+    int kbeg = 0, kend = p.K;
+    if (p.epilogue == EPI_SPLITK) {
+        kbeg = split * p.k_chunk;
+        kend = min(p.K, kbeg + p.k_chunk);
+    }
+    const int nkt = kend > kbeg ? (kend - kbeg) / 16 : 0;  // whole tiles only (checked by the host)
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[0][0][r] = 0.f;
+
+    if (nkt > 0) {
+        const DmaLoader<A_KC, 64, 256, 16> da(p.A, p.lda, m0, p.M, p.K, kbeg, tid);
+        const DmaLoader<B_KC, 64, 256, 16> db(p.B, p.ldb, n0, p.N, p.K, kbeg, tid);
+        const int last = nkt - 1;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            da.issue(lds[s], s < last ? s : last, wave);
+            db.issue(lds[s] + 64 * 16, s < last ? s : last, wave);
+        }
+        float fa[2][4], fb[2][4];
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile 0
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dma_frag<A_KC, 64, 16>(fa[0], lds[0], wm * 32, 0, lane);
+        dma_frag<B_KC, 64, 16>(fb[0], lds[0] + 64 * 16, wn * 32, 0, lane);
+        auto at = [&](int t) { return t < last ? t : last; };
+        int kt = 0;
+        for (; kt + RING <= nkt; kt += RING) {
+            ring_tile<A_KC, B_KC, 0>(lds, da, db, acc[0][0], fa, fb, at(kt + 4), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 1>(lds, da, db, acc[0][0], fa, fb, at(kt + 5), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 2>(lds, da, db, acc[0][0], fa, fb, at(kt + 6), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 3>(lds, da, db, acc[0][0], fa, fb, at(kt + 7), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 4>(lds, da, db, acc[0][0], fa, fb, at(kt + 8), wave, wm, wn, lane);
+        }
+        if (kt < nkt) ring_tile<A_KC, B_KC, 0>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
+        if (kt + 1 < nkt) ring_tile<A_KC, B_KC, 1>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
+        if (kt + 2 < nkt) ring_tile<A_KC, B_KC, 2>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
+        if (kt + 3 < nkt) ring_tile<A_KC, B_KC, 3>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
+        // the tiles fetched past the end are still landing: let them, before the LDS is handed back
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    epilogue<1, 1>(p, acc, m0, n0, split, wm * 32, wn * 32, lane, 64);
+}
+template __global__ void gemm_dma_ring_kernel<true, true>(const KernelArgs);
+template __global__ void gemm_dma_ring_kernel<true, false>(const KernelArgs);
+template __global__ void gemm_dma_ring_kernel<false, false>(const KernelArgs);
 
 // ================================================================================================
 // Generic path: guarded buffer loads -> registers -> LDS, 128x128 tiles
@@ -436,7 +527,7 @@ void launch_dma16(const KernelArgs& ka, int grid) {
 }
 template <bool A_KC, bool B_KC>
 void launch_dma_small(const KernelArgs& ka, int grid) {
-    hipLaunchKernelGGL((gemm_dma_kernel<A_KC, B_KC, 2, 2, 1, 1, 16>), dim3(grid), dim3(256), 0, stream(), ka);
+    hipLaunchKernelGGL((gemm_dma_ring_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, stream(), ka);
 }
 
 // does an operand meet the DMA path's needs: 16-byte aligned base and rows; for KS also a row count
