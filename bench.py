@@ -362,9 +362,10 @@ def bf16_workload(args, lib, torch):
     dom = max(gemm, key=lambda k: gemm[k][0])
     achieved = gemm[dom][2] / (gemm[dom][0] * 1e-3) / 1e12
     labels = {
-        "gemm_fwd": "gemm_bf16_nt8_kernel<swish / store> (forward layers: v_mfma_f32_16x16x32_bf16, persistent 256x256 "
-                    "tiles, four-slot LDS-DMA ring of 32-step slices)",
-        "gemm_dgrad": "gemm_bf16_nt8_kernel<store / swish'> (data gradients: the same kernel on transposed weight copies)",
+        "gemm_fwd": "gemm_bf16_nt8_kernel<swish and swish' / store / swish + output layer's sums> (forward layers: "
+                    "v_mfma_f32_16x16x32_bf16, persistent 256x256 tiles, four-slot LDS-DMA ring of 32-step slices)",
+        "gemm_dgrad": "gemm_bf16_nt8_kernel<store / times the stored swish'> (data gradients: the same kernel on transposed "
+                      "weight copies)",
         "gemm_wgrad": "wgrad_bf16_kernel<2, 4, 4, 2> (v_mfma_f32_32x32x16_bf16, 256x256 tiles, ds_read_b64_tr_b16 operands)",
     }
     # HBM side of the same products: operands read once, results written once, per point of a micro-batch
@@ -373,7 +374,10 @@ def bf16_workload(args, lib, torch):
     elems_per_point = ((pe_ld + 2 * hidden) + (hidden + inter) + (inter + hidden) + (hidden + inter)
                        + (inter + 2 * hidden) + 2 * (hidden + inter) + (hidden + pe_ld))
     product_bytes = 2.0 * elems_per_point * micro * S * n_micro * steps
-    traffic, _, traffic_file = pmc_traffic("gemm_bf16_nt8_kernel<1>", "bf16_cfg5_")
+    # the first hidden layer's forward product (two output streams): epilogue 5 since it stores swish' beside the swish
+    traffic, _, traffic_file = pmc_traffic("gemm_bf16_nt8_kernel<5>", "bf16_cfg5_")
+    if traffic is None:
+        traffic, _, traffic_file = pmc_traffic("gemm_bf16_nt8_kernel<1>", "bf16_cfg5_")
     out = ({
         "metric": "trained rays/s @256 samples/ray, bf16 operands", "value": rays_total * steps / el, "unit": "rays/s",
         "n_gpus": 1, "steps": steps, "warmup": min(args.warmup, 1), "ms_per_step": el / steps * 1e3,
@@ -385,7 +389,8 @@ def bf16_workload(args, lib, torch):
         "roofline": {"bound": "mfma", "kernel": labels.get(dom, dom), "achieved": achieved,
                      "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
                      "traffic": traffic,
-                     "traffic_unit": "HBM-side bytes per launch of gemm_bf16_nt8_kernel<swish> (L2 fetches x2 + writes)",
+                     "traffic_unit": "HBM-side bytes per launch of the first hidden layer's forward product, "
+                                     "gemm_bf16_nt8_kernel<swish and swish'> (L2 fetches x2 + writes)",
                      "traffic_source": traffic_file and f"{traffic_file}: counters of an earlier run of this workload",
                      "all_gemm_tflops": all_work / (all_ms * 1e-3) / 1e12, "gemm_share_of_step": all_ms / (el * 1e3),
                      "products_against_hbm": {
