@@ -28,7 +28,7 @@ SUMMARY_STEPS=16 run "bf16_cfg5_" "${R}_bf16" --workload bf16 --micro-batches 4
     -d "$ROOT/gpurun_out/prof_${R}_ref16" -o stats -- python3 "$ROOT/bench.py" --rays 16 --steps 2000 --warmup 200 \
     --no-cpu-baseline --no-secondary > "$ROOT/gpurun_out/prof_${R}_ref16.log" 2>&1 )
 cp "gpurun_out/prof_${R}_ref16/stats_kernel_stats.csv" "profiles/${R}_ref16_kernel_stats.csv"
-tail -1 "gpurun_out/prof_${R}_ref16.log" > "profiles/${R}_ref16_bench_line_under_profiler.json"
+grep "^{\"metric" "gpurun_out/prof_${R}_ref16.log" > "profiles/${R}_ref16_bench_line_under_profiler.json"
 python3 bench.py --rays 16 --steps 2000 --warmup 200 --no-cpu-baseline --no-secondary > "profiles/${R}_ref16_bench_line.json" 2>> gpurun_out/bench_line.err
 # the bench lines themselves, unprofiled
 python3 bench.py > "profiles/${R}_bench_line.json" 2> gpurun_out/bench_line.err
