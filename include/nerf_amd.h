@@ -185,6 +185,11 @@ int nerf_composite_forward(const float* d_raw, int out_dim, const float* d_targe
 int nerf_loss_accumulate(const float* d_err, int R, float* d_loss);
 /* activation + volume_rendering_gradient_kernel (nerf.c:63-127) from the raw output (out_dim 4) */
 int nerf_composite_backward(const float* d_raw, int out_dim, const float* d_err, float* d_error_output, int R, int S);
+/* nerf_composite_forward (without d_dens / d_rgb) and nerf_composite_backward as ONE launch: the gradient of a
+ * ray needs only that ray's own pixel error (train.c:204-212 launches the two kernels back to back).  Writes
+ * d_pixel, d_err and d_error_output with exactly the values the two calls write. */
+int nerf_composite_forward_backward(const float* d_raw, int out_dim, const float* d_target, int target_stride,
+                                    float* d_pixel, float* d_err, float* d_error_output, int R, int S);
 
 /* ---- opt-in quadrature with the true sample spacing: NOT the reference's arithmetic (which uses the
  * constant 0.01 and stops at transmittance 0.01).  delta_s = t_{s+1} - t_s with the depths
@@ -196,6 +201,10 @@ int nerf_composite_forward_spacing(const float* d_raw, int out_dim, const float*
                                    float* d_err, int R, int S);
 int nerf_composite_backward_spacing(const float* d_raw, int out_dim, const float* d_offsets, float near_plane,
                                     float far_plane, const float* d_err, float* d_error_output, int R, int S);
+/* the two calls above as one launch (as nerf_composite_forward_backward) */
+int nerf_composite_forward_backward_spacing(const float* d_raw, int out_dim, const float* d_offsets, float near_plane,
+                                            float far_plane, const float* d_target, int target_stride, float* d_pixel,
+                                            float* d_err, float* d_error_output, int R, int S);
 /* d_offsets[i] = uniform [0,1) for i < count, a pure function of (seed, batch, i): stratified
  * sampling (one jittered sample per spacing interval) when passed as d_offsets.  The reference
  * samples without jitter (nerf.c:187). */

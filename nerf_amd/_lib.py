@@ -144,6 +144,9 @@ _SIGS = {
     "nerf_composite_backward_spacing": (C.c_int, [VP, C.c_int, VP, C.c_float, C.c_float, VP, VP, C.c_int, C.c_int]),
     "nerf_stratified_offsets": (C.c_int, [VP, C.c_long, C.c_ulonglong, C.c_ulonglong]),
     "nerf_composite_backward": (C.c_int, [VP, C.c_int, VP, VP, C.c_int, C.c_int]),
+    "nerf_composite_forward_backward": (C.c_int, [VP, C.c_int, VP, C.c_int, VP, VP, VP, C.c_int, C.c_int]),
+    "nerf_composite_forward_backward_spacing": (C.c_int, [VP, C.c_int, VP, C.c_float, C.c_float, VP, C.c_int, VP, VP, VP,
+                                                          C.c_int, C.c_int]),
     "activation_kernel_launch": (None, [VP, VP, VP, C.c_int, C.c_int]),
     "volume_rendering_and_loss_launch": (None, [VP, VP, VP, VP, VP, VP, C.c_int, C.c_int]),
     "volume_rendering_gradient_launch": (None, [VP, VP, VP, VP, C.c_int, C.c_int]),

@@ -202,15 +202,13 @@ struct SpacingArgs {
     float near_plane, far_plane;
 };
 
-template <int SPL, bool RAW, bool SPACING>
-__global__ __launch_bounds__(256) void composite_forward_kernel(
+// One ray's forward pass on one wavefront.  WANT_E: the pixel error is also handed back in every lane
+// (e[c] = pixel[c] - target[c], the value lanes 0..2 store), for a gradient that follows in the same kernel.
+template <int SPL, bool RAW, bool SPACING, bool WANT_E>
+__device__ __forceinline__ void composite_forward_ray(
     const float* __restrict__ raw, int out_dim, const float* __restrict__ dens_in, const float* __restrict__ rgb_in,
     const float* __restrict__ target, int target_stride, float* __restrict__ dens_out, float* __restrict__ rgb_out,
-    float* __restrict__ pixel, float* __restrict__ err, int R, int S, SpacingArgs sp) {
-    const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= R) return;  // whole wavefront leaves together
-
+    float* __restrict__ pixel, float* __restrict__ err, int S, SpacingArgs sp, int lane, int ray, float (&e)[3]) {
     // samples past the end of the ray re-read the last one (a valid address, no branch around the
     // load) and get alpha = 0, which takes them out of every sum and product below
     f32x4 y[SPL];
@@ -268,6 +266,23 @@ __global__ __launch_bounds__(256) void composite_forward_kernel(
         pixel[ray * 3 + lane] = a;
         if (err) err[ray * 3 + lane] = a - target[(size_t)ray * target_stride + lane];  // nerf.c:54-55
     }
+    if (WANT_E) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) e[c] = acc[c] - target[(size_t)ray * target_stride + c];
+    }
+}
+
+template <int SPL, bool RAW, bool SPACING>
+__global__ __launch_bounds__(256) void composite_forward_kernel(
+    const float* __restrict__ raw, int out_dim, const float* __restrict__ dens_in, const float* __restrict__ rgb_in,
+    const float* __restrict__ target, int target_stride, float* __restrict__ dens_out, float* __restrict__ rgb_out,
+    float* __restrict__ pixel, float* __restrict__ err, int R, int S, SpacingArgs sp) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;  // whole wavefront leaves together
+    float e[3];
+    composite_forward_ray<SPL, RAW, SPACING, false>(raw, out_dim, dens_in, rgb_in, target, target_stride, dens_out, rgb_out,
+                                                    pixel, err, S, sp, lane, ray, e);
 }
 
 // loss[0] += sum of squares of err[0..n): one workgroup, fixed summation order (reproducible;
@@ -286,15 +301,11 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
     if (threadIdx.x == 0) loss[0] = accumulate ? loss[0] + part[0] : part[0];
 }
 
+// One ray's gradient on one wavefront, from the ray's pixel error (e0, e1, e2)
 template <int SPL, bool RAW, bool SPACING>
-__global__ __launch_bounds__(256) void composite_backward_kernel(
+__device__ __forceinline__ void composite_backward_ray(
     const float* __restrict__ raw, int out_dim, const float* __restrict__ dens_in, const float* __restrict__ rgb_in,
-    const float* __restrict__ err, float* __restrict__ d_out, int R, int S, SpacingArgs sp) {
-    const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ray >= R) return;
-    const float e0 = err[ray * 3 + 0], e1 = err[ray * 3 + 1], e2 = err[ray * 3 + 2];
-
+    const float e0, const float e1, const float e2, float* __restrict__ d_out, int S, SpacingArgs sp, int lane, int ray) {
     f32x4 y[SPL];  // as in the forward kernel: all loads first, clamped to the ray
 #pragma unroll
     for (int i = 0; i < SPL; i++) {
@@ -405,6 +416,34 @@ __global__ __launch_bounds__(256) void composite_backward_kernel(
     }
 }
 
+template <int SPL, bool RAW, bool SPACING>
+__global__ __launch_bounds__(256) void composite_backward_kernel(
+    const float* __restrict__ raw, int out_dim, const float* __restrict__ dens_in, const float* __restrict__ rgb_in,
+    const float* __restrict__ err, float* __restrict__ d_out, int R, int S, SpacingArgs sp) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    composite_backward_ray<SPL, RAW, SPACING>(raw, out_dim, dens_in, rgb_in, err[ray * 3 + 0], err[ray * 3 + 1],
+                                              err[ray * 3 + 2], d_out, S, sp, lane, ray);
+}
+
+// Forward pass and gradient of a ray in one launch, for the training step (the gradient of a ray needs that
+// ray's pixel error and nothing of any other ray): the two routines above one after the other on the same
+// wavefront, so every value is the one the two kernels compute -- the samples, their activations and
+// exponentials are simply still in registers -- and a launch and a second read of the MLP's output are saved.
+template <int SPL, bool SPACING>
+__global__ __launch_bounds__(256) void composite_forward_backward_kernel(
+    const float* __restrict__ raw, int out_dim, const float* __restrict__ target, int target_stride,
+    float* __restrict__ pixel, float* __restrict__ err, float* __restrict__ d_out, int R, int S, SpacingArgs sp) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ray >= R) return;
+    float e[3];
+    composite_forward_ray<SPL, true, SPACING, true>(raw, out_dim, nullptr, nullptr, target, target_stride, nullptr, nullptr,
+                                                    pixel, err, S, sp, lane, ray, e);
+    composite_backward_ray<SPL, true, SPACING>(raw, out_dim, nullptr, nullptr, e[0], e[1], e[2], d_out, S, sp, lane, ray);
+}
+
 __global__ __launch_bounds__(256) void activation_kernel(const float* __restrict__ y, float* __restrict__ dens,
                                                          float* __restrict__ rgb, int n, int out_dim) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -472,6 +511,25 @@ int launch_backward(const float* raw, int out_dim, const float* dens_in, const f
         default: return NERF_ERR_ARG;
     }
 #undef BWD
+    return NERF_OK;
+}
+
+template <bool SPACING>
+int launch_forward_backward(const float* raw, int out_dim, const float* target, int target_stride, float* pixel, float* err,
+                            float* d_out, int R, int S, SpacingArgs sp = SpacingArgs{nullptr, 0.0f, 0.0f}) {
+    const dim3 grid((R + 3) / 4), block(256);
+#define FB(SPL)                                                                                                  \
+    hipLaunchKernelGGL((composite_forward_backward_kernel<SPL, SPACING>), grid, block, 0, stream(), raw, out_dim, \
+                       target, target_stride, pixel, err, d_out, R, S, sp)
+    switch (spl_for(S)) {
+        case 1: FB(1); break;
+        case 2: FB(2); break;
+        case 4: FB(4); break;
+        case 8: FB(8); break;
+        case 16: FB(16); break;
+        default: return NERF_ERR_ARG;
+    }
+#undef FB
     return NERF_OK;
 }
 
@@ -563,6 +621,24 @@ int nerf_stratified_offsets(float* d_offsets, long count, unsigned long long see
     if (!d_offsets || count <= 0) return NERF_ERR_ARG;
     hipLaunchKernelGGL(stratified_offsets_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream(),
                        d_offsets, count, seed, batch);
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+int nerf_composite_forward_backward(const float* d_raw, int out_dim, const float* d_target, int target_stride,
+                                    float* d_pixel, float* d_err, float* d_error_output, int R, int S) {
+    if (R <= 0 || S <= 0 || out_dim != 4 || !d_raw || !d_target || !d_pixel || !d_err || !d_error_output) return NERF_ERR_ARG;
+    const int rc = launch_forward_backward<false>(d_raw, out_dim, d_target, target_stride, d_pixel, d_err, d_error_output, R, S);
+    if (rc != NERF_OK) return rc;
+    return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+int nerf_composite_forward_backward_spacing(const float* d_raw, int out_dim, const float* d_offsets, float near_plane,
+                                            float far_plane, const float* d_target, int target_stride, float* d_pixel,
+                                            float* d_err, float* d_error_output, int R, int S) {
+    if (R <= 0 || S <= 1 || out_dim != 4 || !d_raw || !d_target || !d_pixel || !d_err || !d_error_output) return NERF_ERR_ARG;
+    const int rc = launch_forward_backward<true>(d_raw, out_dim, d_target, target_stride, d_pixel, d_err, d_error_output, R, S,
+                                                 SpacingArgs{d_offsets, near_plane, far_plane});
+    if (rc != NERF_OK) return rc;
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 

@@ -106,7 +106,9 @@ PitchedInput encoded_input(NerfTrainer* tr) {
     return in;
 }
 
-// Compositing, loss and the compositing gradient on the MLP's raw output (train.c:192-212).
+// Compositing, loss and the compositing gradient on the MLP's raw output (train.c:192-212).  The
+// gradient of a ray needs that ray's own pixel error only, so forward pass and gradient are one launch;
+// the loss (a sum over the rays) follows.
 int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int accumulate) {
     const NerfTrainerConfig& c = tr->cfg;
     const int R = c.rays_per_batch, S = c.num_samples;
@@ -114,23 +116,15 @@ int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int a
     float* loss = tr->d_grads + tr->n_params;  // the three floats behind it stay zero from nerf_trainer_create on
     int rc;
     {
-        ProfScope prof(K_COMPOSITE_FWD, (double)R * S * 16.0 + (double)R * 36.0);
-        rc = spacing ? nerf_composite_forward_spacing(raw, c.output_dim, tr->d_offsets_last, c.near_plane, c.far_plane,
-                                                      tr->d_target, 3, tr->d_pixel, tr->d_err, R, S)
-                     : nerf_composite_forward(raw, c.output_dim, tr->d_target, 3, nullptr, nullptr, tr->d_pixel,
-                                              tr->d_err, R, S);
+        // both kernels' bytes: the raw output read once, its gradient written once
+        ProfScope prof(K_COMPOSITE_FWD, (double)R * S * 32.0 + (double)R * 36.0);
+        rc = spacing ? nerf_composite_forward_backward_spacing(raw, c.output_dim, tr->d_offsets_last, c.near_plane,
+                                                               c.far_plane, tr->d_target, 3, tr->d_pixel, tr->d_err, draw, R, S)
+                     : nerf_composite_forward_backward(raw, c.output_dim, tr->d_target, 3, tr->d_pixel, tr->d_err, draw, R, S);
     }
     if (rc != NERF_OK) return rc;
-    {
-        ProfScope prof(K_LOSS, (double)R * 12.0);
-        rc = loss_sum(tr->d_err, R, loss, accumulate);  // a first micro-batch overwrites: no memset launch
-    }
-    if (rc != NERF_OK) return rc;
-    ProfScope prof(K_COMPOSITE_BWD, (double)R * S * 32.0 + (double)R * 12.0);
-    if (spacing)
-        return nerf_composite_backward_spacing(raw, c.output_dim, tr->d_offsets_last, c.near_plane, c.far_plane, tr->d_err,
-                                               draw, R, S);
-    return nerf_composite_backward(raw, c.output_dim, tr->d_err, draw, R, S);
+    ProfScope prof(K_LOSS, (double)R * 12.0);
+    return loss_sum(tr->d_err, R, loss, accumulate);  // a first micro-batch overwrites: no memset launch
 }
 
 int after_forward_bf16(NerfTrainer* tr, int accumulate) {

@@ -225,9 +225,36 @@ def test_fused_raw_forms_match_launchers(gpu, R, S):
     assert np.array_equal(d_err.numpy(), d_err2.numpy())
     assert np.array_equal(d_loss.numpy(), d_loss2.numpy())
     assert np.array_equal(d_g.numpy(), d_g2.numpy())
+    # forward pass and gradient as one launch (the training step's form): the same bits again
+    d_pix3, d_err3, d_g3 = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray((R * S, 4))
+    assert lib.nerf_composite_forward_backward(d_y.ptr, 4, d_t.ptr, 3, d_pix3.ptr, d_err3.ptr, d_g3.ptr, R, S) == 0
+    assert np.array_equal(d_pix.numpy(), d_pix3.numpy())
+    assert np.array_equal(d_err.numpy(), d_err3.numpy())
+    assert np.array_equal(d_g.numpy(), d_g3.numpy())
+
+
+def test_one_launch_form_on_boundary_and_stopped_rays(gpu):
+    """the one-launch form against the two kernels on rays that stop early and rays inside the guard band"""
+    from nerf_amd.api import DeviceArray
+    from nerf_amd._lib import lib
+    rng = np.random.default_rng(5)
+    R, S = 2048, 128
+    y = random_raw(rng, R, S)
+    y.reshape(R, S, 4)[::3, :, 0] += 30.0  # a third of the rays dense enough to stop within a few samples
+    target = rng.random((R, 3)).astype(np.float32)
+    d_y, d_t = DeviceArray.from_numpy(y), DeviceArray.from_numpy(target)
+    d_pix, d_err, d_g = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray((R * S, 4))
+    assert lib.nerf_composite_forward(d_y.ptr, 4, d_t.ptr, 3, 0, 0, d_pix.ptr, d_err.ptr, R, S) == 0
+    assert lib.nerf_composite_backward(d_y.ptr, 4, d_err.ptr, d_g.ptr, R, S) == 0
+    d_pix3, d_err3, d_g3 = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray((R * S, 4))
+    assert lib.nerf_composite_forward_backward(d_y.ptr, 4, d_t.ptr, 3, d_pix3.ptr, d_err3.ptr, d_g3.ptr, R, S) == 0
+    assert np.array_equal(d_pix.numpy(), d_pix3.numpy())
+    assert np.array_equal(d_err.numpy(), d_err3.numpy())
+    assert np.array_equal(d_g.numpy(), d_g3.numpy())
 
 
 def test_bad_arguments_are_rejected(gpu):
     from nerf_amd._lib import lib
     assert lib.nerf_composite_forward(0, 4, 0, 3, 0, 0, 0, 0, 4, 128) == 1
     assert lib.nerf_composite_backward(0, 4, 0, 0, 4, 128) == 1
+    assert lib.nerf_composite_forward_backward(0, 4, 0, 3, 0, 0, 0, 4, 128) == 1

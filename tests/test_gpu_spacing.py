@@ -29,6 +29,12 @@ def test_spacing_kernels_match_oracle(gpu, oracle, R, S, jitter):
     got = d_g.numpy()
     for c in range(4):  # density and colour gradients live on different scales
         assert np.abs(got[:, c] - g[:, c]).max() <= 1e-4 * np.abs(g[:, c]).max() + 1e-12
+    # the training step's one-launch form: the same bits as the two kernels
+    d_pix2, d_err2, d_g2 = DeviceArray((R, 3)), DeviceArray((R, 3)), DeviceArray((R * S, 4))
+    assert lib.nerf_composite_forward_backward_spacing(d_y.ptr, 4, optr, 2.0, 6.0, d_t.ptr, 3, d_pix2.ptr, d_err2.ptr,
+                                                       d_g2.ptr, R, S) == 0
+    assert np.array_equal(d_pix.numpy(), d_pix2.numpy()) and np.array_equal(d_err.numpy(), d_err2.numpy())
+    assert np.array_equal(got, d_g2.numpy())
 
 
 def test_stratified_offsets_are_uniform_and_reproducible(gpu):
