@@ -110,14 +110,17 @@ struct ReduceJob {
     const float* slabs;
     float* dst;
     size_t stride, n;
-    int splits, accumulate;
+    int splits, accumulate;  // splits == 0: dst[0] (+)= sum of squares of slabs[0..n), the step's squared error
 };
 struct ReduceQueue {
-    static constexpr int MAX_JOBS = 4;
+    static constexpr int MAX_JOBS = 5;
     ReduceJob jobs[MAX_JOBS];
     int count = 0;
     double bytes = 0.0;
     void add(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate);  // flushes first when full
+    // dst[0] = (accumulate ? dst[0] : 0) + sum of squares of x[0..n), in the order (and so with the bits) of
+    // loss_sum's own kernel: the step's loss rides on the slab sums' launch
+    void add_sum_of_squares(const float* x, size_t n, float* dst, int accumulate);
     void flush();
 };
 

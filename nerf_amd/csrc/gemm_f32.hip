@@ -440,7 +440,9 @@ inline bool reduce_vec4(const ReduceJob& q) {
     return q.n % 4 == 0 && q.stride % 4 == 0 && aligned_to(q.slabs, 16) && aligned_to(q.dst, 16);
 }
 inline bool reduce_grouped(const ReduceJob& q) { return q.splits >= REDUCE_GROUPED_FROM && reduce_vec4(q); }
+inline int reduce_mode(const ReduceJob& q) { return q.splits == 0 ? 3 : reduce_grouped(q) ? 2 : reduce_vec4(q) ? 1 : 0; }
 inline unsigned reduce_blocks(const ReduceJob& q) {
+    if (q.splits == 0) return 1;
     if (reduce_grouped(q)) return (unsigned)((q.n / 4 + 15) / 16);
     return (unsigned)(((reduce_vec4(q) ? q.n / 4 : q.n) + 255) / 256);
 }
@@ -459,9 +461,35 @@ __device__ __forceinline__ f32x4 sum_slabs4(const float* __restrict__ slabs, siz
     return s;
 }
 
-// mode: 0 one element per thread, 1 four per thread, 2 grouped
+// mode: 0 one element per thread, 1 four per thread, 2 grouped, 3 sum of squares (one workgroup)
 __device__ __forceinline__ void reduce_job(const ReduceJob& q, int mode, unsigned block) {
     __shared__ f32x4 part[REDUCE_GROUPS][16];
+    if (mode == 3) {
+        // The order of loss_reduce_kernel (composite.hip), whose 1024 threads each add every 1024th square and
+        // then halve 512, 256, ... 1 times through LDS: thread t here plays its threads t, t + 256, t + 512 and
+        // t + 768, takes the first two halvings in registers and the rest through LDS -- the same sums, the
+        // same bits.
+        float* tree = reinterpret_cast<float*>(part);
+        const int t = threadIdx.x;
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        for (size_t i = t; i < q.n; i += 1024) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const size_t k = i + 256 * j;
+                if (k < q.n) p[j] += q.slabs[k] * q.slabs[k];
+            }
+        }
+        p[0] += p[2];
+        p[1] += p[3];
+        tree[t] = p[0] + p[1];
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if (t < w) tree[t] += tree[t + w];
+            __syncthreads();
+        }
+        if (t == 0) q.dst[0] = q.accumulate ? q.dst[0] + tree[0] : tree[0];
+        return;
+    }
     if (mode == 2) {
         const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
         const size_t i = ((size_t)block * 16 + c) * 4;
@@ -618,8 +646,7 @@ int gemm_f32(const GemmArgs& g) {
 
 void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {
     const ReduceJob q{slabs, dst, stride, n, splits, accumulate};
-    const int mode = reduce_grouped(q) ? 2 : reduce_vec4(q) ? 1 : 0;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(reduce_blocks(q)), dim3(256), 0, stream(), q, mode);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(reduce_blocks(q)), dim3(256), 0, stream(), q, reduce_mode(q));
 }
 
 void ReduceQueue::add(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {
@@ -628,10 +655,16 @@ void ReduceQueue::add(const float* slabs, int splits, size_t stride, float* dst,
     bytes += (double)n * splits * 4.0;
 }
 
+void ReduceQueue::add_sum_of_squares(const float* x, size_t n, float* dst, int accumulate) {
+    if (count == MAX_JOBS) flush();
+    jobs[count++] = ReduceJob{x, dst, 0, n, 0, accumulate};
+    bytes += (double)n * 4.0;
+}
+
 void ReduceQueue::flush() {
     if (count == 0) return;
     ProfScope prof(K_REDUCE, bytes);
-    if (count == 1) {
+    if (count == 1 && jobs[0].splits > 0) {
         reduce_slabs(jobs[0].slabs, jobs[0].splits, jobs[0].stride, jobs[0].dst, jobs[0].n, jobs[0].accumulate);
     } else {
         ReduceBatch b = {};
@@ -640,7 +673,7 @@ void ReduceQueue::flush() {
         for (int j = 0; j < count; j++) {
             const ReduceJob& q = jobs[j];
             b.job[j] = q;
-            b.mode[j] = reduce_grouped(q) ? 2 : reduce_vec4(q) ? 1 : 0;
+            b.mode[j] = reduce_mode(q);
             b.first_block[j] = blocks;
             blocks += reduce_blocks(q);
         }

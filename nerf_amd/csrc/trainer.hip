@@ -108,8 +108,9 @@ PitchedInput encoded_input(NerfTrainer* tr) {
 
 // Compositing, loss and the compositing gradient on the MLP's raw output (train.c:192-212).  The
 // gradient of a ray needs that ray's own pixel error only, so forward pass and gradient are one launch;
-// the loss (a sum over the rays) follows.
-int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int accumulate) {
+// the loss (a sum over the rays) follows -- on the slab sums' launch at the end of the backward pass when
+// there is a queue for those (nothing on the device reads the loss before), else as a launch of its own.
+int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int accumulate, ReduceQueue* sums = nullptr) {
     const NerfTrainerConfig& c = tr->cfg;
     const int R = c.rays_per_batch, S = c.num_samples;
     const bool spacing = c.quadrature == NERF_QUADRATURE_SPACING;
@@ -123,6 +124,10 @@ int composite_and_gradient(NerfTrainer* tr, const float* raw, float* draw, int a
                      : nerf_composite_forward_backward(raw, c.output_dim, tr->d_target, 3, tr->d_pixel, tr->d_err, draw, R, S);
     }
     if (rc != NERF_OK) return rc;
+    if (sums) {
+        sums->add_sum_of_squares(tr->d_err, (size_t)R * 3, loss, accumulate);
+        return NERF_OK;
+    }
     ProfScope prof(K_LOSS, (double)R * 12.0);
     return loss_sum(tr->d_err, R, loss, accumulate);  // a first micro-batch overwrites: no memset launch
 }
@@ -188,9 +193,9 @@ int after_forward_fused(NerfTrainer* tr, int accumulate) {
         must(mlp_gemm(g, math), "fused pair, forward");
     }
     skinny_forward(m2->d_layer_preact, m2->d_W2, m2->d_layer_output, N, H, O, true);
-    const int rc = composite_and_gradient(tr, m2->d_layer_output, m2->d_error_output, accumulate);
+    ReduceQueue sums;  // the loss, the output layer's and the encoding layer's slab sums: one launch at the end
+    const int rc = composite_and_gradient(tr, m2->d_layer_output, m2->d_error_output, accumulate, &sums);
     if (rc != NERF_OK) return rc;
-    ReduceQueue sums;  // the output layer's and the encoding layer's slab sums: one launch at the end
     skinny_backward(m2->d_error_output, m2->d_layer_preact, m2->d_W2, m2->d_error_hidden, m2->d_W2_grad, N, H, O,
                     m2->d_workspace, accumulate, tr->words != 0, &sums);
     weight_gradient(m2->d_error_hidden, H, m1->d_layer_postact, H, H, N, tr->d_dwc, tr->d_pair_ws, 0, math,
@@ -231,11 +236,11 @@ int after_forward(NerfTrainer* tr, int accumulate) {
     if (tr->cfg.fuse_linear_pair) return after_forward_fused(tr, accumulate);
     mlp_forward(tr->mlp1, encoded_input(tr));
     mlp_forward(tr->mlp2, tr->mlp1->d_layer_output);
-    const int rc = composite_and_gradient(tr, tr->mlp2->d_layer_output, tr->mlp2->d_error_output, accumulate);
-    if (rc != NERF_OK) return rc;
-    // the four weight gradients' slab sums wait for each other and go as one launch: nothing reads a
-    // gradient before the step's backward pass is over
+    // the loss and the four weight gradients' slab sums wait for each other and go as one launch: nothing
+    // reads either before the step's backward pass is over
     ReduceQueue sums;
+    const int rc = composite_and_gradient(tr, tr->mlp2->d_layer_output, tr->mlp2->d_error_output, accumulate, &sums);
+    if (rc != NERF_OK) return rc;
     mlp_backward(tr->mlp2, tr->mlp1->d_layer_output, tr->mlp2->input_dim, tr->mlp1->d_error_output, accumulate, &sums);
     mlp_backward(tr->mlp1, tr->d_pe, tr->pe_ld, nullptr, accumulate, &sums);
     sums.flush();

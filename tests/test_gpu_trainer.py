@@ -199,6 +199,29 @@ def test_step_is_reproducible(gpu, oracle):
     assert s1 == s2 and np.array_equal(g1, g2)
 
 
+@pytest.mark.parametrize("R", [16, 341, 1500])
+def test_step_loss_has_the_bits_of_the_loss_kernel(gpu, oracle_fast, R):
+    """the step's squared error is summed on the slab sums' launch, in the order of the loss kernel
+    (nerf_loss_accumulate) that the reference's call sequence uses: the same bits, also when a second
+    micro-batch adds to it"""
+    from nerf_amd._lib import lib
+    from nerf_amd.api import DeviceArray, Trainer
+    p = Pair(gpu, oracle_fast, R, 32, Lp=4, Ld=2, hidden=64, inter=64)
+    d_idx = DeviceArray.from_numpy(p.indices(3))
+    p.tr.forward_backward(p.dds, d_idx)
+    _, sse = p.tr.get_grads()
+    d_err = DeviceArray.from_numpy(p.tr.buffer(Trainer.BUF_ERR))
+    d_loss = DeviceArray.zeros((1,))
+    assert lib.nerf_loss_accumulate(d_err.ptr, R, d_loss.ptr) == 0
+    assert np.float32(sse) == d_loss.numpy()[0] and sse > 0
+    p.tr.forward_backward_add(p.dds, DeviceArray.from_numpy(p.indices(4)))
+    _, sse2 = p.tr.get_grads()
+    d_err = DeviceArray.from_numpy(p.tr.buffer(Trainer.BUF_ERR))
+    assert lib.nerf_loss_accumulate(d_err.ptr, R, d_loss.ptr) == 0
+    assert np.float32(sse2) == d_loss.numpy()[0] and sse2 > sse
+    p.tr.destroy()
+
+
 def test_create_rejects_bad_config(gpu):
     from nerf_amd.api import trainer_config
     from nerf_amd._lib import lib
