@@ -18,6 +18,8 @@
 // Status codes of the int-returning entry points.
 enum { NERF_OK = 0, NERF_ERR_ARG = 1, NERF_ERR_HIP = 2, NERF_ERR_IO = 3 };
 
+struct NerfDeviceDataset;  // encode.hip
+
 namespace nerf {
 
 // The stream every launch of the library goes to (set by nerf_set_stream; default: null stream).
@@ -132,6 +134,13 @@ int wgrad_tile_n(int cols);
 struct WgradPlan { int splits, k_chunk, tile_n; };
 WgradPlan plan_weight_gradient(int rows_out, int cols, long batch);
 WgradPlan plan_weight_gradient_split(int rows_out, int cols, long batch);  // for gemm_split's tile shapes
+
+// nerf_encode_batch (fp32 encoding, include/nerf_amd.h) with a copy riding on the launch:
+// copy_dst[r * copy_ld_dst + c] = copy_src[r * copy_cols + c] for a [copy_rows][copy_cols] matrix
+int encode_batch_with_copy(const NerfDeviceDataset* dds, const int* d_idx, const float* d_offsets, int R, int S,
+                           float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe,
+                           float* d_target, const float* copy_src, float* copy_dst, int copy_rows, int copy_cols,
+                           int copy_ld_dst);
 
 // ---- bf16 matrix products (bf16 operands in memory, fp32 accumulation) --------------------------
 typedef unsigned short bf16_t;  // storage type of a bf16 value

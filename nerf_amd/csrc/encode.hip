@@ -66,6 +66,13 @@ struct EncodeArgs {
     int ld_pe;
     float* target;                      // [R][3] or null (SRC_INDICES only)
     float* batch_X_out;                 // [N][6] or null: also emit the raw samples
+    // rider: dst[r][c] = src[r][c] for a [rows][cols] matrix into rows of ld_dst floats, done by extra
+    // workgroups of the same launch (the trainer's re-pitched copy of the first layer's weights: a launch of
+    // its own costs as much as this whole kernel at the reference's batch size)
+    const float* copy_src;
+    float* copy_dst;
+    int copy_rows, copy_cols, copy_ld_dst;
+    unsigned encode_blocks;             // workgroups that encode; those from here on copy
 };
 
 __device__ __forceinline__ void ray_through_pixel(const DeviceCamera& cam, int u, int v, float (&o)[3], float (&d)[3]) {
@@ -195,6 +202,14 @@ template <int BF16>
 __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a, const int P, const int row_ld) {
     __shared__ float sample[ENC_POINTS][6];
     extern __shared__ float rows[];  // [P][row_ld]
+    if (blockIdx.x >= a.encode_blocks) {  // the rider: one element per thread
+        const long long i = (long long)(blockIdx.x - a.encode_blocks) * 256 + threadIdx.x;
+        if (i < (long long)a.copy_rows * a.copy_cols) {
+            const int r = (int)(i / a.copy_cols), c = (int)(i - (long long)r * a.copy_cols);
+            a.copy_dst[(size_t)r * a.copy_ld_dst + c] = a.copy_src[i];
+        }
+        return;
+    }
     const long long n_points = (long long)a.R * a.S;
     const long long p0 = (long long)blockIdx.x * P;
     if (threadIdx.x < P && p0 + threadIdx.x < n_points) {
@@ -283,7 +298,8 @@ __global__ __launch_bounds__(256) void pe_vector_kernel(const float* __restrict_
     out[dim + 2 * dim * l + 2 * i + 1] = cv;
 }
 
-int launch_encode(const EncodeArgs& a) {
+int launch_encode(const EncodeArgs& args) {
+    EncodeArgs a = args;
     if (a.R <= 0 || a.S <= 0 || (a.source != SRC_POINTS && a.S <= 1) || a.pos_l < 0 || a.dir_l < 0 ||
         a.pos_l > 30 || a.dir_l > 30 || (!a.pe && !a.batch_X_out))
         return NERF_ERR_ARG;
@@ -292,7 +308,12 @@ int launch_encode(const EncodeArgs& a) {
     const int row_ld = (NERF_PE_DIM3(a.pos_l) + NERF_PE_DIM3(a.dir_l)) | 1;
     const int P = (size_t)ENC_POINTS * row_ld * 4 <= 60 * 1024 ? ENC_POINTS : ENC_POINTS / 2;
     const size_t lds = a.pe ? (size_t)P * row_ld * 4 : 0;
-    const long long grid = ((long long)a.R * a.S + P - 1) / P;
+    long long grid = ((long long)a.R * a.S + P - 1) / P;
+    a.encode_blocks = (unsigned)grid;
+    if (a.copy_src) {
+        if (!a.copy_dst || a.copy_rows <= 0 || a.copy_cols <= 0 || a.copy_ld_dst < a.copy_cols) return NERF_ERR_ARG;
+        grid += ((long long)a.copy_rows * a.copy_cols + 255) / 256;
+    }
     if (grid > 0x7fffffffLL) return NERF_ERR_ARG;
     if (a.pe_format == PE_BF16)
         hipLaunchKernelGGL(encode_kernel<PE_BF16>, dim3((unsigned)grid), dim3(256), lds, stream(), a, P, row_ld);
@@ -378,6 +399,26 @@ int nerf_encode_batch(const NerfDeviceDataset* dds, const int* d_idx, const floa
     a.batch_X_out = d_batch_X;
     return launch_encode(a);
 }
+
+}  // extern "C"
+
+// nerf_encode_batch (fp32 encoding) with a matrix copy riding on the launch (common.hpp)
+int nerf::encode_batch_with_copy(const NerfDeviceDataset* dds, const int* d_idx, const float* d_offsets, int R, int S,
+                                 float near_plane, float far_plane, int pos_enc_l, int dir_enc_l, float* d_pe, int ld_pe,
+                                 float* d_target, const float* copy_src, float* copy_dst, int copy_rows, int copy_cols,
+                                 int copy_ld_dst) {
+    if (!dds || !d_idx || !d_pe || !copy_src) return NERF_ERR_ARG;
+    if (d_target && !dds->d_pixels) return NERF_ERR_ARG;
+    EncodeArgs a = {};
+    a.source = SRC_INDICES;
+    a.cams = dds->d_cams; a.pixels = dds->d_pixels; a.img_off = dds->d_img_off; a.idx = d_idx;
+    a.offsets = d_offsets; a.R = R; a.S = S; a.near_plane = near_plane; a.far_plane = far_plane;
+    a.pos_l = pos_enc_l; a.dir_l = dir_enc_l; a.pe = d_pe; a.ld_pe = ld_pe; a.target = d_target;
+    a.copy_src = copy_src; a.copy_dst = copy_dst; a.copy_rows = copy_rows; a.copy_cols = copy_cols; a.copy_ld_dst = copy_ld_dst;
+    return launch_encode(a);
+}
+
+extern "C" {
 
 // nerf_encode_batch writing the encoding as split words (the split-bf16 products' pre-split operands)
 int nerf_encode_batch_split(const NerfDeviceDataset* dds, const int* d_idx, const float* d_offsets, int R, int S,

@@ -42,6 +42,7 @@ struct NerfTrainer {
     int pe_ld;        // floats per row of d_pe: pe_dim rounded up to 32 (150 -> 160), tail zero
     float* d_pe;      // [N][pe_ld]
     float* d_w1p;     // [H][pe_ld] copy of mlp1.W1 with the same pitch (nullptr when pe_ld == pe_dim)
+    bool w1p_fresh;   // d_w1p was refreshed by the encoder's launch of the step in hand (else encoded_input copies)
     float* d_target;  // [R][3]
     float* d_pixel;   // [R][3]
     float* d_err;     // [R][3]
@@ -96,7 +97,10 @@ void fill_rand(float* w, int fan_out, int fan_in) {
 // that a data-parallel broadcast or a checkpoint load rewrites between steps.
 PitchedInput encoded_input(NerfTrainer* tr) {
     PitchedInput in = {tr->d_pe, tr->pe_ld, tr->mlp1->d_W1};
-    if (tr->d_w1p) {
+    if (tr->d_w1p && tr->w1p_fresh) {  // the encoder's launch of this very step has made the copy
+        tr->w1p_fresh = false;
+        in.W1 = tr->d_w1p;
+    } else if (tr->d_w1p) {
         NERF_HIP_CHECK(hipMemcpy2DAsync(tr->d_w1p, (size_t)tr->pe_ld * 4, tr->mlp1->d_W1, (size_t)tr->pe_dim * 4,
                                         (size_t)tr->pe_dim * 4, tr->cfg.hidden_dim, hipMemcpyDeviceToDevice,
                                         stream()));
@@ -440,7 +444,13 @@ static int forward_backward_impl(NerfTrainer* tr, const NerfDeviceDataset* datas
         else if (tr->words)
             rc = nerf_encode_batch_split(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane,
                                          c.far_plane, c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld, tr->d_target);
-        else
+        else if (tr->d_w1p) {
+            // the re-pitched copy of the first layer's weights (encoded_input) rides on this launch
+            rc = encode_batch_with_copy(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane, c.far_plane,
+                                        c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld, tr->d_target, tr->mlp1->d_W1,
+                                        tr->d_w1p, c.hidden_dim, tr->pe_dim, tr->pe_ld);
+            tr->w1p_fresh = rc == NERF_OK;
+        } else
             rc = nerf_encode_batch(dataset, d_idx, d_offsets, c.rays_per_batch, c.num_samples, c.near_plane, c.far_plane,
                                    c.pos_enc_l, c.dir_enc_l, tr->d_pe, tr->pe_ld, tr->d_target, nullptr);
     }
