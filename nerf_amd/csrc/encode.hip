@@ -188,7 +188,7 @@ __device__ __forceinline__ void encode_coordinate(float x, int L, float* dst) {
     }
 }
 
-// A workgroup owns `P` (64, or 32 for very long rows) consecutive points.
+// A workgroup owns `P` (64; 32 for very long rows; 16 for small batches) consecutive points.
 // Phase 1: one thread per point builds the sample (ray through the pixel, depth, position) once and
 //          parks position and direction in LDS.
 // Phase 2: one thread per (coordinate, point) writes that coordinate's identity column and all its
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncodeArgs a, const i
     const int pos_w = NERF_PE_DIM3(a.pos_l), pe_dim = pos_w + NERF_PE_DIM3(a.dir_l);
     const long long left = n_points - p0;
     const int here = left < P ? (int)left : P;
-    const int shift = P == 64 ? 6 : 5;
+    const int shift = P == 64 ? 6 : (P == 32 ? 5 : 4);
     for (int item = threadIdx.x; item < 6 * P; item += 256) {
         const int c = item >> shift, pt = item & (P - 1);  // coordinate 0-2 position, 3-5 direction
         if (pt >= here) continue;
@@ -306,7 +306,10 @@ int launch_encode(const EncodeArgs& args) {
     if (a.pe && a.ld_pe < NERF_PE_DIM3(a.pos_l) + NERF_PE_DIM3(a.dir_l)) return NERF_ERR_ARG;
     // LDS image of the rows: odd stride, at most 60 KB (rows of up to 366 floats: 64 or 32 points)
     const int row_ld = (NERF_PE_DIM3(a.pos_l) + NERF_PE_DIM3(a.dir_l)) | 1;
-    const int P = (size_t)ENC_POINTS * row_ld * 4 <= 60 * 1024 ? ENC_POINTS : ENC_POINTS / 2;
+    int P = (size_t)ENC_POINTS * row_ld * 4 <= 60 * 1024 ? ENC_POINTS : ENC_POINTS / 2;
+    // a batch too small to give every CU two workgroups of 64 points is cut into workgroups of 16: a workgroup's
+    // time is a chain of waits (ray set-up, one round of octaves, the stores), shorter with fewer points each
+    if ((long long)a.R * a.S < 512LL * ENC_POINTS) P = 16;
     const size_t lds = a.pe ? (size_t)P * row_ld * 4 : 0;
     long long grid = ((long long)a.R * a.S + P - 1) / P;
     a.encode_blocks = (unsigned)grid;
