@@ -199,6 +199,36 @@ def test_step_is_reproducible(gpu, oracle):
     assert s1 == s2 and np.array_equal(g1, g2)
 
 
+@pytest.mark.parametrize("R,S,hidden,inter,precision", [(16, 128, 512, 512, 0), (40, 33, 64, 128, 0), (16, 128, 256, 256, 2)])
+def test_step_is_forward_backward_then_update_bit_for_bit(gpu, oracle_fast, R, S, hidden, inter, precision):
+    """nerf_trainer_step = the learning-rate schedule + nerf_trainer_forward_backward + nerf_trainer_update:
+    weights, gradients and loss equal bit for bit, three steps on"""
+    from nerf_amd.api import DeviceArray
+    a = Pair(gpu, oracle_fast, R, S, Lp=4, Ld=2, hidden=hidden, inter=inter, precision=precision)
+    b = Pair(gpu, oracle_fast, R, S, Lp=4, Ld=2, hidden=hidden, inter=inter, precision=precision)
+    lr = np.float32(1e-4)
+    for step in range(3):
+        d_idx = DeviceArray.from_numpy(a.indices(50 + step))
+        a.tr.step(a.dds, d_idx)
+        if step % 10000 == 0:
+            lr = np.float32(lr * np.float32(0.99))
+        b.tr.forward_backward(b.dds, d_idx)
+        b.tr.update(float(lr))
+        ga, sa = a.tr.get_grads()
+        gb, sb = b.tr.get_grads()
+        assert sa == sb and np.array_equal(ga, gb)
+        assert np.array_equal(a.tr.get_params(), b.tr.get_params())
+    assert a.tr.mlp(0).t == 3 and a.tr.mlp(1).t == 3
+    # and the moments: one more separate update on both must keep them equal
+    d_idx = DeviceArray.from_numpy(a.indices(60))
+    for t in (a.tr, b.tr):
+        t.forward_backward(a.dds if t is a.tr else b.dds, d_idx)
+        t.update(float(lr))
+    assert np.array_equal(a.tr.get_params(), b.tr.get_params())
+    a.tr.destroy()
+    b.tr.destroy()
+
+
 @pytest.mark.parametrize("R", [16, 341, 1500])
 def test_step_loss_has_the_bits_of_the_loss_kernel(gpu, oracle_fast, R):
     """the step's squared error is summed on the slab sums' launch, in the order of the loss kernel
