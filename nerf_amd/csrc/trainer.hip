@@ -435,6 +435,7 @@ static int forward_backward_impl(NerfTrainer* tr, const NerfDeviceDataset* datas
     if (!tr || !dataset || !d_idx) return NERF_ERR_ARG;
     const NerfTrainerConfig& c = tr->cfg;
     tr->d_offsets_last = d_offsets;
+    tr->w1p_fresh = false;
     int rc;
     {
         ProfScope prof(K_ENCODE, (double)c.rays_per_batch * c.num_samples * tr->pe_dim * (tr->bf ? 2.0 : 4.0));
@@ -474,6 +475,7 @@ int nerf_trainer_forward_backward_points(NerfTrainer* tr, const float* d_batch_X
     if (tr->cfg.quadrature != NERF_QUADRATURE_REFERENCE) return NERF_ERR_ARG;  // the spacing needs the depths, not points
     const NerfTrainerConfig& c = tr->cfg;
     const int N = c.rays_per_batch * c.num_samples;
+    tr->w1p_fresh = false;  // this encoder launch carries no copy of the first layer's weights: encoded_input makes it
     int rc;
     {
         ProfScope prof(K_ENCODE, (double)N * tr->pe_dim * 4.0);
