@@ -96,6 +96,20 @@ enum MatrixMath {
 
 // Enqueues the product; returns NERF_OK or NERF_ERR_ARG (unsupported shape/alignment).
 int gemm_f32(const GemmArgs& args);
+// While a GemmPairScope is alive, a weight-gradient product (both operands strided) that takes gemm_f32's
+// small-tile kernel is held back one call: if a data-gradient product (A k-contiguous, small tiles too) comes
+// next, the two go out as ONE launch whose workgroups are shared out between them.  At the batch sizes that kernel serves, a product
+// is one short workgroup per CU and most of what it costs beyond its matrix instructions is the start and
+// the end of its launch; two products that do not depend on each other overlap those.  The caller vouches
+// that a data gradient which directly follows a weight gradient inside the scope neither reads what that
+// one writes nor writes what it reads, and that no other kind of launch made inside the scope reads a weight
+// gradient of the scope.  Anything still held back goes out
+// when the scope ends, in the order the calls were made.
+struct GemmPairScope {
+    explicit GemmPairScope(bool enable = true);
+    ~GemmPairScope();
+    bool on_;
+};
 
 // The same product in split-bf16 arithmetic (gemm_split.hip).  Needs 16-byte aligned operands and K a
 // multiple of 32 (gemm_split_supported); callers fall back to gemm_f32 otherwise.

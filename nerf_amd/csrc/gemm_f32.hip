@@ -183,14 +183,13 @@ __device__ __forceinline__ void ring_tile(float (&lds)[RING][RING_TILE], const D
 }
 
 template <bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256, 3) void gemm_dma_ring_kernel(const KernelArgs ka) {
-    __shared__ __attribute__((aligned(16))) float lds[RING][RING_TILE];
+__device__ __forceinline__ void ring_product(const KernelArgs& ka, float (&lds)[RING][RING_TILE], int block) {
     const GemmArgs& p = ka.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int tm, tn, split;
-    decode_block(ka, blockIdx.x, tm, tn, split);
+    decode_block(ka, block, tm, tn, split);
     const int m0 = tm * 64, n0 = tn * 64;
     int kbeg = 0, kend = p.K;
     if (p.epilogue == EPI_SPLITK) {
@@ -235,6 +234,23 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_ring_kernel(const KernelArgs 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     epilogue<1, 1>(p, acc, m0, n0, split, wm * 32, wn * 32, lane, 64);
+}
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 3) void gemm_dma_ring_kernel(const KernelArgs ka) {
+    __shared__ __attribute__((aligned(16))) float lds[RING][RING_TILE];
+    ring_product<A_KC, B_KC>(ka, lds, blockIdx.x);
+}
+
+// Two products that do not depend on each other as one launch: the first blocks_a workgroups work on the
+// first (a weight gradient: both operands strided), the rest on the second (a data gradient: A k-contiguous).
+struct PairArgs {
+    KernelArgs a, b;
+    unsigned blocks_a;
+};
+__global__ __launch_bounds__(256, 3) void gemm_dma_ring_pair_kernel(const PairArgs pa) {
+    __shared__ __attribute__((aligned(16))) float lds[RING][RING_TILE];
+    if (blockIdx.x < pa.blocks_a) ring_product<false, false>(pa.a, lds, blockIdx.x);
+    else ring_product<true, false>(pa.b, lds, blockIdx.x - pa.blocks_a);
 }
 template __global__ void gemm_dma_ring_kernel<true, true>(const KernelArgs);
 template __global__ void gemm_dma_ring_kernel<true, false>(const KernelArgs);
@@ -553,9 +569,49 @@ template <bool A_KC, bool B_KC>
 void launch_dma16(const KernelArgs& ka, int grid) {
     hipLaunchKernelGGL((gemm_dma_kernel<A_KC, B_KC, 2, 2, 2, 2, 16>), dim3(grid), dim3(256), 0, stream(), ka);
 }
-template <bool A_KC, bool B_KC>
-void launch_dma_small(const KernelArgs& ka, int grid) {
-    hipLaunchKernelGGL((gemm_dma_ring_kernel<A_KC, B_KC>), dim3(grid), dim3(256), 0, stream(), ka);
+// the small-tile products held back by a GemmPairScope (one at most)
+struct HeldProduct {
+    KernelArgs ka;
+    int grid, a_kc, b_kc;
+    bool held;
+};
+thread_local int g_pair_depth = 0;
+thread_local HeldProduct g_held = {};
+
+void launch_ring_single(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_dma_ring_kernel<true, true>), dim3(grid), dim3(256), 0, stream(), ka);
+    else if (a_kc) hipLaunchKernelGGL((gemm_dma_ring_kernel<true, false>), dim3(grid), dim3(256), 0, stream(), ka);
+    else hipLaunchKernelGGL((gemm_dma_ring_kernel<false, false>), dim3(grid), dim3(256), 0, stream(), ka);
+}
+void release_held() {
+    if (!g_held.held) return;
+    g_held.held = false;
+    launch_ring_single(g_held.ka, g_held.grid, g_held.a_kc, g_held.b_kc);
+}
+void launch_dma_small(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
+    if (g_pair_depth == 0) {
+        launch_ring_single(ka, grid, a_kc, b_kc);
+        return;
+    }
+    // Only a weight gradient (both operands strided) is held back, and only a data gradient (A k-contiguous)
+    // that comes right after it joins it: that is the order in which the backward pass makes two products
+    // from one error matrix.  The other order -- a data gradient, then the weight gradient of the layer
+    // below, which READS that data gradient -- must never share a launch.
+    const bool strided = !a_kc && !b_kc, half = a_kc && !b_kc;
+    if (g_held.held) {
+        if (half) {
+            PairArgs pa;
+            pa.a = g_held.ka;
+            pa.b = ka;
+            pa.blocks_a = (unsigned)g_held.grid;
+            g_held.held = false;
+            hipLaunchKernelGGL(gemm_dma_ring_pair_kernel, dim3((unsigned)(g_held.grid + grid)), dim3(256), 0, stream(), pa);
+            return;
+        }
+        release_held();
+    }
+    if (strided) g_held = HeldProduct{ka, grid, a_kc, b_kc, true};
+    else launch_ring_single(ka, grid, a_kc, b_kc);
 }
 
 // does an operand meet the DMA path's needs: 16-byte aligned base and rows; for KS also a row count
@@ -614,14 +670,13 @@ int gemm_f32(const GemmArgs& g) {
     if (g.epilogue == EPI_SPLITK) grid *= g.splits;
     if (grid > 0x7fffffffL) return NERF_ERR_ARG;
     const int gi = (int)grid;
+    if (!(dma && small)) release_held();  // launches keep the order of the calls
     if (dma) {
         // 16-step K-tiles (32 KB of LDS, four workgroups per CU) for the products that store a
         // point-major result: more co-resident workgroups hide the epilogue's stores.  The
         // weight gradient (both operands strided, slab epilogue) is faster on 32-step tiles.
         if (wide) launch_dma<false, false, 4, 1, 1, 5>(ka, gi);
-        else if (small && g.a_kc && g.b_kc) launch_dma_small<true, true>(ka, gi);
-        else if (small && g.a_kc) launch_dma_small<true, false>(ka, gi);
-        else if (small) launch_dma_small<false, false>(ka, gi);
+        else if (small) launch_dma_small(ka, gi, g.a_kc, g.b_kc);
         else if (g.a_kc && g.b_kc) launch_dma16<true, true>(ka, gi);
         else if (g.a_kc) launch_dma16<true, false>(ka, gi);
         else launch_dma<false, false, 2, 2, 2, 2>(ka, gi);
@@ -642,6 +697,18 @@ int gemm_f32(const GemmArgs& g) {
         }
     }
     return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
+GemmPairScope::GemmPairScope(bool enable) : on_(enable) {
+    if (on_) g_pair_depth++;
+}
+GemmPairScope::~GemmPairScope() {
+    if (on_ && --g_pair_depth == 0 && g_held.held) {
+        // the caller's own timing scope closed when the product was held back: its launch is timed here (a
+        // held product is a weight gradient), with no work added a second time
+        ProfScope prof(K_GEMM_WGRAD, 0.0);
+        release_held();
+    }
 }
 
 void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {

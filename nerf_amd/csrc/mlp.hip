@@ -406,6 +406,10 @@ void mlp_backward(MLP* mlp, const float* d_X, int ld_X, float* d_grad_X, int acc
     const int in = mlp->input_dim, hid = mlp->hidden_dim, out = mlp->output_dim;
     float* ws_output = (float*)mlp->d_workspace;
     float* ws_hidden = (float*)((char*)mlp->d_workspace + output_layer_slab_bytes(hid, out, (int)B));
+    // A weight gradient and the data gradient that follows it read the same error matrix and write different
+    // things: at small batches they go out as one launch.  Only with a queue for the slab sums: without one
+    // every weight gradient is followed by the launch that sums its slabs.
+    const GemmPairScope pair(queue != nullptr);
     if (skinny_ok(hid, out)) {
         skinny_backward(mlp->d_error_output, mlp->d_layer_preact, mlp->d_W2, mlp->d_error_hidden, mlp->d_W2_grad, B,
                         hid, out, ws_output, accumulate, false, queue);
