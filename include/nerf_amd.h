@@ -40,6 +40,11 @@ void nerf_host_free(void* p);
 void nerf_host_api_release(void);
 int nerf_memcpy_h2d(void* dst, const void* src, size_t bytes); /* synchronous, like cudaMemcpy */
 int nerf_memcpy_d2h(void* dst, const void* src, size_t bytes);
+/* the copy of nerf_memcpy_h2d enqueued on the stream without waiting for it: `src` must be page-locked
+ * (nerf_host_alloc) and stay untouched until the stream has passed the copy (nerf_event_record right after
+ * it, nerf_event_synchronize before the buffer is written again).  No counterpart in train.c, whose copies
+ * are synchronous (train.c:182-185): with it a driver can draw the next batches while the GPU works. */
+int nerf_memcpy_h2d_async(void* dst, const void* src, size_t bytes);
 int nerf_memcpy_d2d(void* dst, const void* src, size_t bytes); /* asynchronous on the stream */
 int nerf_memset(void* dst, int value, size_t bytes);           /* asynchronous on the stream */
 int nerf_device_info(char* name256, int* compute_units, int* clock_khz, size_t* total_mem);

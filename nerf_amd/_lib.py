@@ -84,6 +84,7 @@ _SIGS = {
     "nerf_device_malloc": (VP, [C.c_size_t]),
     "nerf_device_free": (None, [VP]),
     "nerf_memcpy_h2d": (C.c_int, [VP, VP, C.c_size_t]),
+    "nerf_memcpy_h2d_async": (C.c_int, [VP, VP, C.c_size_t]),
     "nerf_host_alloc": (VP, [C.c_size_t]),
     "nerf_host_free": (None, [VP]),
     "nerf_host_api_release": (None, []),

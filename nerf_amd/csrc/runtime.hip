@@ -106,6 +106,10 @@ int nerf_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     return hipStreamSynchronize(nerf::g_stream) == hipSuccess ? NERF_OK : NERF_ERR_HIP;
 }
 
+int nerf_memcpy_h2d_async(void* dst, const void* src, size_t bytes) {
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, nerf::g_stream) == hipSuccess ? NERF_OK : NERF_ERR_HIP;
+}
+
 int nerf_memcpy_d2h(void* dst, const void* src, size_t bytes) {
     if (hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, nerf::g_stream) != hipSuccess) return NERF_ERR_HIP;
     return hipStreamSynchronize(nerf::g_stream) == hipSuccess ? NERF_OK : NERF_ERR_HIP;

@@ -343,11 +343,29 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
 
     ClassicBuffers cb;
     memset(&cb, 0, sizeof(cb));
-    int* idx = NULL;
-    int* d_idx = NULL;
+    /* The device-side step needs 12 bytes per ray from the host.  They travel through a ring of IDX_SLOTS
+     * page-locked host buffers, each with its own device buffer and an event recorded behind its copy: the
+     * copy is enqueued without waiting (train.c:182-185 copies synchronously, which drains the GPU every
+     * step), and a slot is drawn into again only after the stream has passed its previous copy.  The host
+     * thus draws the next batches while the GPU works on this one; it is waited for only where the loss is
+     * read. */
+    enum { IDX_SLOTS = 4 };
+    int* idx_ring[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
+    int* d_idx_ring[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
+    void* idx_copied[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
+    int idx_used[IDX_SLOTS] = {0, 0, 0, 0};
+    long slot_counter = 0;
+    const size_t idx_bytes = (size_t)o.rays * 3 * sizeof(int);
     if (o.fused) {
-        idx = (int*)malloc((size_t)o.rays * 3 * sizeof(int));
-        d_idx = (int*)device_alloc_or_die((size_t)o.rays * 3 * sizeof(int));
+        for (int k = 0; k < IDX_SLOTS; k++) {
+            idx_ring[k] = (int*)nerf_host_alloc(idx_bytes);
+            d_idx_ring[k] = (int*)device_alloc_or_die(idx_bytes);
+            idx_copied[k] = nerf_event_create();
+            if (!idx_ring[k] || !idx_copied[k]) {
+                fprintf(stderr, "Failed to allocate the ray-index buffers\n");
+                return -1;
+            }
+        }
     } else {
         classic_alloc(&cb, o.rays, o.samples, pe_dim, o.pin);
     }
@@ -374,21 +392,29 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
         if (o.fused && o.virtual_ranks > 0) {
             /* what `shards` ranks do, one after the other: every shard is cut from the same global draw */
             for (int v = 0; v < shards; v++) {
+                const int k = (int)(slot_counter++ % IDX_SLOTS);
+                if (idx_used[k]) CHECK_HIP(nerf_event_synchronize(idx_copied[k]));
                 srand(batch_seed(seed_base, batch));
-                if (nerf_draw_ray_indices_shard(ds, o.rays * shards, v, shards, idx) != 0) return -1;
-                CHECK_HIP(nerf_memcpy_h2d(d_idx, idx, (size_t)o.rays * 3 * sizeof(int)));
-                if (v == 0) CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx, NULL));
-                else CHECK_HIP(nerf_trainer_forward_backward_add(trainer, dds, d_idx, NULL));
+                if (nerf_draw_ray_indices_shard(ds, o.rays * shards, v, shards, idx_ring[k]) != 0) return -1;
+                CHECK_HIP(nerf_memcpy_h2d_async(d_idx_ring[k], idx_ring[k], idx_bytes));
+                CHECK_HIP(nerf_event_record(idx_copied[k]));
+                idx_used[k] = 1;
+                if (v == 0) CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx_ring[k], NULL));
+                else CHECK_HIP(nerf_trainer_forward_backward_add(trainer, dds, d_idx_ring[k], NULL));
             }
             CHECK_HIP(nerf_trainer_update(trainer, lr, points * shards));
         } else if (o.fused) {
+            const int k = (int)(slot_counter++ % IDX_SLOTS);
+            if (idx_used[k]) CHECK_HIP(nerf_event_synchronize(idx_copied[k]));
             if (dp) { /* this rank's block of the global batch */
-                if (nerf_draw_ray_indices_shard(ds, o.rays * world, rank, world, idx) != 0) return -1;
+                if (nerf_draw_ray_indices_shard(ds, o.rays * world, rank, world, idx_ring[k]) != 0) return -1;
             } else {
-                nerf_draw_ray_indices(ds, o.rays, idx);
+                nerf_draw_ray_indices(ds, o.rays, idx_ring[k]);
             }
-            CHECK_HIP(nerf_memcpy_h2d(d_idx, idx, (size_t)o.rays * 3 * sizeof(int)));
-            CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx, NULL));
+            CHECK_HIP(nerf_memcpy_h2d_async(d_idx_ring[k], idx_ring[k], idx_bytes));
+            CHECK_HIP(nerf_event_record(idx_copied[k]));
+            idx_used[k] = 1;
+            CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx_ring[k], NULL));
             if (dp) CHECK_HIP(nerf_dp_allreduce_grads(dp, trainer)); /* gradients and squared error of all ranks */
             CHECK_HIP(nerf_trainer_update(trainer, lr, points * world));
         } else {
@@ -429,8 +455,11 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
 
     if (dp) nerf_dp_destroy(dp);
     if (o.fused) {
-        free(idx);
-        nerf_device_free(d_idx);
+        for (int k = 0; k < IDX_SLOTS; k++) {
+            nerf_host_free(idx_ring[k]);
+            nerf_device_free(d_idx_ring[k]);
+            nerf_event_destroy(idx_copied[k]);
+        }
         nerf_dataset_release(dds);
         nerf_trainer_destroy(trainer);
     } else {
