@@ -35,6 +35,8 @@ GEMM_KERNEL = {
     "gemm_fwd": "gemm_dma_kernel<true, true, 2, 2, 2, 2, 16>",
     "gemm_dgrad": "gemm_dma_kernel<true, false, 2, 2, 2, 2, 16>",
     "gemm_wgrad": "gemm_dma_kernel<false, false, 2, 2, 2, 2, 32>",
+    # a layer's weight gradient and the data gradient made from the same error matrix, one launch
+    "gemm_pair": "gemm_dma_pair_kernel",
 }
 SPLIT_KERNEL = {
     "gemm_fwd": "gemm_split_kernel<true, true, 2, 4, 4, 2, false>",
@@ -600,12 +602,17 @@ def main():
         achieved = dwork / (dms * 1e-3) / 1e12
         all_ms = sum(v[0] for v in gemm.values())
         all_work = sum(v[2] for v in gemm.values())
-        names = (SPLIT_WORDS_KERNEL if fused else SPLIT_KERNEL) if split else GEMM_KERNEL
+        names = dict(GEMM_KERNEL)
+        if split:
+            names.update(SPLIT_WORDS_KERNEL if fused else SPLIT_KERNEL)
         mode = ("fused_" if fused else "") + ("split_" if split else "")
         traffic, mfma_util, traffic_file = pmc_traffic(names[dom], mode)
         prof_ms, prof_file = rocprof_avg_ms(names[dom], mode)
         ksteps = 32 if dom == "gemm_wgrad" else 16
         kernel_label = f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x{ksteps} tiles, LDS-DMA staged)"
+        if dom == "gemm_pair":
+            kernel_label += ("; one launch = the split-K weight gradient of a layer and the data gradient that the "
+                             "backward pass makes from the same error matrix, 512 + 16384 workgroups")
         peak = PEAK_F32_MFMA_TFLOPS
         if split:
             # three bf16 products are executed per algorithmic product: price the executed work

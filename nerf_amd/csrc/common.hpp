@@ -41,6 +41,7 @@ enum KernelId {
     K_LOSS,
     K_COMPOSITE_BWD,
     K_ADAMW,
+    K_GEMM_PAIR,  // a weight gradient and the data gradient that follows it as one launch (GemmPairScope)
     K_COUNT
 };
 struct ProfScope {
@@ -50,6 +51,12 @@ struct ProfScope {
     void* start_;
     double work_;
 };
+// What gemm_f32 tells the ProfScope its caller has open around the call.  prof_discard_scope(): the
+// product was held back and nothing was launched -- the scope records nothing.  prof_redirect_scope(id,
+// extra): what was launched is a pair -- the scope records its time under `id`, with `extra` (the held
+// product's work) added to its own.
+void prof_discard_scope();
+void prof_redirect_scope(int id, double extra_work);
 
 // ---- fp32 MFMA matrix product ---------------------------------------------------------------
 // C = A (x) B over a contraction of length K.

@@ -91,18 +91,17 @@ __device__ __forceinline__ void k_tile(float (&lds)[2][(WM * MI + WN * NI) * 32 
     __syncthreads();
 }
 
-template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int BKT = BK>
-__global__ __launch_bounds__(256, BKT == 32 ? 2 : 3) void gemm_dma_kernel(const KernelArgs ka) {
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int BKT>
+__device__ __forceinline__ void dma_product(const KernelArgs& ka, float (&lds)[2][(WM * MI + WN * NI) * 32 * BKT], int block) {
     constexpr int BM_ = WM * MI * 32, BN_ = WN * NI * 32;
-    constexpr int A_TILE = BM_ * BKT, B_TILE = BN_ * BKT;
+    constexpr int A_TILE = BM_ * BKT;
     static_assert(WM * WN == 4 && (BM_ == 128 || BM_ == 64), "four wavefronts, 128- or 64-row tiles");
-    __shared__ __attribute__((aligned(16))) float lds[2][A_TILE + B_TILE];
     const GemmArgs& p = ka.g;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the DMA's LDS address scalar
     const int wm = wave / WN, wn = wave % WN;
     int tm, tn, split;
-    decode_block(ka, blockIdx.x, tm, tn, split);
+    decode_block(ka, block, tm, tn, split);
     const int m0 = tm * BM_, n0 = tn * BN_;
     int kbeg = 0, kend = p.K;
     if (p.epilogue == EPI_SPLITK) {
@@ -137,6 +136,24 @@ __global__ __launch_bounds__(256, BKT == 32 ? 2 : 3) void gemm_dma_kernel(const 
     }
     if (kt < nkt) k_tile<A_KC, B_KC, WM, WN, MI, NI, 0, BKT>(lds, da, db, acc, kt, wave, wm, wn, lane);
     epilogue<MI, NI>(p, acc, m0, n0, split, wm * MI * 32, wn * NI * 32, lane, BM_);
+}
+
+template <bool A_KC, bool B_KC, int WM, int WN, int MI, int NI, int BKT = BK>
+__global__ __launch_bounds__(256, BKT == 32 ? 2 : 3) void gemm_dma_kernel(const KernelArgs ka) {
+    __shared__ __attribute__((aligned(16))) float lds[2][(WM * MI + WN * NI) * 32 * BKT];
+    dma_product<A_KC, B_KC, WM, WN, MI, NI, BKT>(ka, lds, blockIdx.x);
+}
+
+// A split-K weight gradient and the data gradient that follows it in the backward pass as one launch of
+// 128x128 tiles, both on 16-step K-tiles (four workgroups per CU): see GemmPairScope.
+struct PairArgs {
+    KernelArgs a, b;
+    unsigned blocks_a;
+};
+__global__ __launch_bounds__(256, 3) void gemm_dma_pair_kernel(const PairArgs pa) {
+    __shared__ __attribute__((aligned(16))) float lds[2][256 * 16];
+    if (blockIdx.x < pa.blocks_a) dma_product<false, false, 2, 2, 2, 2, 16>(pa.a, lds, blockIdx.x);
+    else dma_product<true, false, 2, 2, 2, 2, 16>(pa.b, lds, blockIdx.x - pa.blocks_a);
 }
 
 // explicit instantiations (hipcc 7.2 drops the host stubs of some implicitly instantiated variants)
@@ -243,10 +260,6 @@ __global__ __launch_bounds__(256, 3) void gemm_dma_ring_kernel(const KernelArgs 
 
 // Two products that do not depend on each other as one launch: the first blocks_a workgroups work on the
 // first (a weight gradient: both operands strided), the rest on the second (a data gradient: A k-contiguous).
-struct PairArgs {
-    KernelArgs a, b;
-    unsigned blocks_a;
-};
 __global__ __launch_bounds__(256, 3) void gemm_dma_ring_pair_kernel(const PairArgs pa) {
     __shared__ __attribute__((aligned(16))) float lds[RING][RING_TILE];
     if (blockIdx.x < pa.blocks_a) ring_product<false, false>(pa.a, lds, blockIdx.x);
@@ -574,6 +587,8 @@ struct HeldProduct {
     KernelArgs ka;
     int grid, a_kc, b_kc;
     bool held;
+    bool big;  // 128x128 tiles (gemm_dma_kernel) instead of the 64x64 ring kernel
+    double work() const { return 2.0 * ka.g.M * ka.g.N * (double)ka.g.K; }
 };
 thread_local int g_pair_depth = 0;
 thread_local HeldProduct g_held = {};
@@ -586,7 +601,31 @@ void launch_ring_single(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
 void release_held() {
     if (!g_held.held) return;
     g_held.held = false;
-    launch_ring_single(g_held.ka, g_held.grid, g_held.a_kc, g_held.b_kc);
+    // the caller's own timing scope recorded nothing when the product was held back (a held product is a
+    // weight gradient): its launch is timed, and its work counted, here
+    ProfScope prof(K_GEMM_WGRAD, g_held.work());
+    if (g_held.big) hipLaunchKernelGGL((gemm_dma_kernel<false, false, 2, 2, 2, 2>), dim3(g_held.grid), dim3(256), 0, stream(), g_held.ka);
+    else launch_ring_single(g_held.ka, g_held.grid, g_held.a_kc, g_held.b_kc);
+}
+// the large-tile counterparts of launch_dma_small: a split-K weight gradient is held back, a data gradient
+// that comes right after it joins it
+bool hold_big_wgrad(const KernelArgs& ka, int grid) {
+    if (g_pair_depth == 0) return false;
+    release_held();
+    g_held = HeldProduct{ka, grid, 0, 0, true, true};
+    prof_discard_scope();  // nothing launched: the pair's launch (or the release) accounts for this product
+    return true;
+}
+bool join_big_dgrad(const KernelArgs& ka, int grid) {
+    if (!g_held.held || !g_held.big) return false;
+    PairArgs pa;
+    pa.a = g_held.ka;
+    pa.b = ka;
+    pa.blocks_a = (unsigned)g_held.grid;
+    g_held.held = false;
+    prof_redirect_scope(K_GEMM_PAIR, g_held.work());
+    hipLaunchKernelGGL(gemm_dma_pair_kernel, dim3((unsigned)(g_held.grid + grid)), dim3(256), 0, stream(), pa);
+    return true;
 }
 void launch_dma_small(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
     if (g_pair_depth == 0) {
@@ -598,6 +637,7 @@ void launch_dma_small(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
     // from one error matrix.  The other order -- a data gradient, then the weight gradient of the layer
     // below, which READS that data gradient -- must never share a launch.
     const bool strided = !a_kc && !b_kc, half = a_kc && !b_kc;
+    if (g_held.held && g_held.big) release_held();
     if (g_held.held) {
         if (half) {
             PairArgs pa;
@@ -605,12 +645,16 @@ void launch_dma_small(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
             pa.b = ka;
             pa.blocks_a = (unsigned)g_held.grid;
             g_held.held = false;
+            prof_redirect_scope(K_GEMM_PAIR, g_held.work());
             hipLaunchKernelGGL(gemm_dma_ring_pair_kernel, dim3((unsigned)(g_held.grid + grid)), dim3(256), 0, stream(), pa);
             return;
         }
         release_held();
     }
-    if (strided) g_held = HeldProduct{ka, grid, a_kc, b_kc, true};
+    if (strided) {
+        g_held = HeldProduct{ka, grid, a_kc, b_kc, true, false};
+        prof_discard_scope();
+    }
     else launch_ring_single(ka, grid, a_kc, b_kc);
 }
 
@@ -670,7 +714,11 @@ int gemm_f32(const GemmArgs& g) {
     if (g.epilogue == EPI_SPLITK) grid *= g.splits;
     if (grid > 0x7fffffffL) return NERF_ERR_ARG;
     const int gi = (int)grid;
+    const bool big_wgrad = dma && !small && !wide && !g.a_kc && !g.b_kc && g.epilogue == EPI_SPLITK;
+    const bool big_dgrad = dma && !small && g.a_kc && !g.b_kc;
+    if (big_dgrad && join_big_dgrad(ka, gi)) return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
     if (!(dma && small)) release_held();  // launches keep the order of the calls
+    if (big_wgrad && hold_big_wgrad(ka, gi)) return NERF_OK;
     if (dma) {
         // 16-step K-tiles (32 KB of LDS, four workgroups per CU) for the products that store a
         // point-major result: more co-resident workgroups hide the epilogue's stores.  The
@@ -703,12 +751,7 @@ GemmPairScope::GemmPairScope(bool enable) : on_(enable) {
     if (on_) g_pair_depth++;
 }
 GemmPairScope::~GemmPairScope() {
-    if (on_ && --g_pair_depth == 0 && g_held.held) {
-        // the caller's own timing scope closed when the product was held back: its launch is timed here (a
-        // held product is a weight gradient), with no work added a second time
-        ProfScope prof(K_GEMM_WGRAD, 0.0);
-        release_held();
-    }
+    if (on_ && --g_pair_depth == 0) release_held();
 }
 
 void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {

@@ -24,7 +24,10 @@ double g_prof_work[K_COUNT];
 long g_prof_launches[K_COUNT];
 const char* const g_prof_names[K_COUNT] = {
     "encode",        "gemm_fwd",     "gemm_dgrad",     "gemm_wgrad", "reduce_slabs", "skinny_fwd",
-    "skinny_bwd",    "composite_fwd", "loss_reduce",   "composite_bwd", "adamw"};
+    "skinny_bwd",    "composite_fwd", "loss_reduce",   "composite_bwd", "adamw",      "gemm_pair"};
+thread_local bool g_prof_discard = false;
+thread_local int g_prof_redirect = -1;
+thread_local double g_prof_extra = 0.0;
 
 void prof_drain() {
     for (ProfRecord& r : g_prof_pending) {
@@ -53,11 +56,27 @@ ProfScope::ProfScope(int id, double work) : id_(id), start_(nullptr), work_(work
 }
 
 ProfScope::~ProfScope() {
+    const bool discard = g_prof_discard;
+    const int redirect = g_prof_redirect;
+    const double extra = g_prof_extra;
+    g_prof_discard = false;
+    g_prof_redirect = -1;
+    g_prof_extra = 0.0;
     if (!start_) return;
+    if (discard) {
+        (void)hipEventDestroy((hipEvent_t)start_);
+        return;
+    }
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, g_stream);
-    g_prof_pending.push_back(ProfRecord{id_, (hipEvent_t)start_, e, work_});
+    g_prof_pending.push_back(ProfRecord{redirect >= 0 ? redirect : id_, (hipEvent_t)start_, e, work_ + extra});
+}
+
+void prof_discard_scope() { g_prof_discard = true; }
+void prof_redirect_scope(int id, double extra_work) {
+    g_prof_redirect = id;
+    g_prof_extra = extra_work;
 }
 }  // namespace nerf
 
