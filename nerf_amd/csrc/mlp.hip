@@ -65,17 +65,28 @@ __global__ __launch_bounds__(256) void skinny_forward_kernel(const float* __rest
         float acc[OUT];
 #pragma unroll
         for (int o = 0; o < OUT; o++) acc[o] = 0.f;
-        for (int c = sub * 4; c < hidden; c += 64) {
-            f32x4 x = *reinterpret_cast<const f32x4*>(h + c);
-            if (PRE) {
+        // four 16-byte pieces of the row are asked for before the first is used (a lane's share of a
+        // 512-wide row is eight): the sums still take the columns in ascending order
+        for (int c0 = sub * 4; c0 < hidden; c0 += 256) {
+            f32x4 xs[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    x[k] = x[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x[k] * -1.44269504088896340736f));
-            }
+            for (int u = 0; u < 4; u++)
+                if (c0 + u * 64 < hidden) xs[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h + c0 + u * 64));
 #pragma unroll
-            for (int o = 0; o < OUT; o++) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(w2s + o * hidden + c);
-                acc[o] += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+            for (int u = 0; u < 4; u++) {
+                const int c = c0 + u * 64;
+                if (c >= hidden) break;
+                f32x4 x = xs[u];
+                if (PRE) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        x[k] = x[k] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x[k] * -1.44269504088896340736f));
+                }
+#pragma unroll
+                for (int o = 0; o < OUT; o++) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(w2s + o * hidden + c);
+                    acc[o] += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+                }
             }
         }
 #pragma unroll
@@ -113,27 +124,43 @@ __global__ __launch_bounds__(256) void skinny_backward_kernel(const float* __res
     }
     const long r0 = (long)blockIdx.x * rows_per_block;
     const long r1 = min(rows, r0 + rows_per_block);
-    for (long row = r0 + rsub; row < r1; row += rpi) {
-        float e[OUT];
+    // eight points' loads are in flight per thread before the first is used; the points are then taken in
+    // order, so a column's sum over the points associates as in a one-at-a-time walk
+    constexpr int AHEAD = 8;
+    for (long base = r0 + rsub; base < r1; base += (long)rpi * AHEAD) {
+        float e[AHEAD][OUT];
+        f32x4 xs[AHEAD];
 #pragma unroll
-        for (int o = 0; o < OUT; o++) e[o] = E[row * OUT + o];
-        const f32x4 x = *reinterpret_cast<const f32x4*>(Hpre + row * hidden + cg * 4);
-        f32x4 eh;
+        for (int u = 0; u < AHEAD; u++) {
+            const long row = base + (long)u * rpi;
+            if (row < r1) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // sigmoid through the hardware exp2 and reciprocal, as in the matrix products' epilogues
-            // (relative error ~3e-7; the IEEE expf and divisions made this kernel ALU-bound)
-            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x[k] * -1.44269504088896340736f));
-            const float hact = x[k] * sg;
-            const float d = sg + x[k] * sg * (1.0f - sg);
-            float back = e[0] * w2[0][k];
-#pragma unroll
-            for (int o = 1; o < OUT; o++) back += e[o] * w2[o][k];
-            eh[k] = EH_WORDS ? split_word_f(back * d) : back * d;
-#pragma unroll
-            for (int o = 0; o < OUT; o++) acc[o][k] += e[o] * hact;
+                for (int o = 0; o < OUT; o++) e[u][o] = E[row * OUT + o];
+                xs[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hpre + row * hidden + cg * 4));
+            }
         }
-        *reinterpret_cast<f32x4*>(EH + row * hidden + cg * 4) = eh;
+#pragma unroll
+        for (int u = 0; u < AHEAD; u++) {
+            const long row = base + (long)u * rpi;
+            if (row >= r1) break;
+            const f32x4 x = xs[u];
+            f32x4 eh;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // sigmoid through the hardware exp2 and reciprocal, as in the matrix products' epilogues
+                // (relative error ~3e-7; the IEEE expf and divisions made this kernel ALU-bound)
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x[k] * -1.44269504088896340736f));
+                const float hact = x[k] * sg;
+                const float d = sg + x[k] * sg * (1.0f - sg);
+                float back = e[u][0] * w2[0][k];
+#pragma unroll
+                for (int o = 1; o < OUT; o++) back += e[u][o] * w2[o][k];
+                eh[k] = EH_WORDS ? split_word_f(back * d) : back * d;
+#pragma unroll
+                for (int o = 0; o < OUT; o++) acc[o][k] += e[u][o] * hact;
+            }
+            *reinterpret_cast<f32x4*>(EH + row * hidden + cg * 4) = eh;
+        }
     }
     // sum the rpi partials of each column group in a fixed order, write the workgroup's slab
     float* slab = slabs + (size_t)blockIdx.x * OUT * hidden;
