@@ -311,3 +311,45 @@ def test_full_size_step_properties(gpu, oracle_fast, R):
     oracle_fast.free_mlp(m2)
     half.tr.destroy()
     full.tr.destroy()
+
+
+@pytest.mark.parametrize("R", [16, 64, 2048])
+def test_paired_launches_give_the_bits_of_the_interfaces_separate_ones(gpu, oracle_fast, R):
+    """The training step sends a layer's weight gradient and the data gradient made from the same error
+    matrix to the GPU as one launch (64x64 tiles at 16 and 64 rays, 128x128 at 2048); the reference's own
+    call sequence (forward_pass_mlp / backward_pass_mlp, train.c:188-216) launches every product alone.
+    Fed the step's encoded batch and output error, it must arrive at the same gradients bit for bit."""
+    from nerf_amd.api import DeviceArray, Trainer
+    from nerf_amd._lib import lib
+    S = 128
+    p = Pair(gpu, oracle_fast, R, S, n_images=4)
+    p.tr.forward_backward(p.dds, DeviceArray.from_numpy(p.indices(77)))
+    grads, _ = p.tr.get_grads()
+    params = p.tr.get_params()
+    pe, draw = p.tr.buffer(Trainer.BUF_PE), p.tr.buffer(Trainer.BUF_DRAW)
+    B = R * S
+    m1, m2 = lib.init_mlp(150, 512, 512, B, None), lib.init_mlp(512, 512, 4, B, None)
+    c1, c2 = m1.contents, m2.contents
+    slices = p.tr.param_slices()
+    for (off, shape), ptr in zip(slices, [c1.d_W1, c1.d_W2, c2.d_W1, c2.d_W2]):
+        DeviceArray(shape, ptr=ptr).upload(params[off:off + shape[0] * shape[1]].reshape(shape))
+    d_X = DeviceArray.from_numpy(np.ascontiguousarray(pe))
+    lib.forward_pass_mlp(m1, d_X.ptr)
+    lib.forward_pass_mlp(m2, c1.d_layer_output)
+    assert np.array_equal(device_rows(c2.d_layer_output, (B, 4)), p.tr.buffer(Trainer.BUF_RAW))
+    DeviceArray((B, 4), ptr=c2.d_error_output).upload(draw)
+    lib.zero_gradients_mlp(m1)
+    lib.zero_gradients_mlp(m2)
+    lib.backward_pass_mlp(m2, c1.d_layer_output, c1.d_error_output)
+    lib.backward_pass_mlp(m1, d_X.ptr, None)
+    for (off, shape), ptr, name in zip(slices, [c1.d_W1_grad, c1.d_W2_grad, c2.d_W1_grad, c2.d_W2_grad],
+                                       ["mlp1 W1", "mlp1 W2", "mlp2 W1", "mlp2 W2"]):
+        assert np.array_equal(device_rows(ptr, shape), grads[off:off + shape[0] * shape[1]].reshape(shape)), name
+    lib.free_mlp(m1)
+    lib.free_mlp(m2)
+    p.tr.destroy()
+
+
+def device_rows(ptr, shape):
+    from nerf_amd.api import device_to_numpy
+    return device_to_numpy(ptr, shape)
