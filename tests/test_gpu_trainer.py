@@ -130,9 +130,11 @@ def test_three_steps_track_the_oracle(gpu, oracle):
     assert np.abs(p.tr.get_params() - p.oracle_params()).max() <= 1e-2 * float(lr)
 
 
-@pytest.mark.parametrize("R,S,Lp,Ld,hidden,inter", [(8, 64, 4, 2, 128, 64), (5, 100, 16, 8, 256, 512), (32, 256, 16, 8, 512, 512)])
+@pytest.mark.parametrize("R,S,Lp,Ld,hidden,inter", [(8, 64, 4, 2, 128, 64), (5, 100, 16, 8, 256, 512), (32, 256, 16, 8, 512, 512),
+                                                   (1311, 100, 16, 8, 512, 512)])
 def test_other_shapes(gpu, oracle_fast, R, S, Lp, Ld, hidden, inter):
-    """ragged sample counts, other widths, S=256; reverse-scan gradient form as the checker"""
+    """ragged sample counts, other widths, S=256, a large batch that no tile size divides (131 100 points:
+    the 128x128-tile kernels with ragged edges); reverse-scan gradient form as the checker"""
     from nerf_amd.api import DeviceArray, Trainer
     p = Pair(gpu, oracle_fast, R, S, Lp, Ld, hidden, inter, acc_f64=True)
     idx = p.indices(R * S)
@@ -313,15 +315,14 @@ def test_full_size_step_properties(gpu, oracle_fast, R):
     full.tr.destroy()
 
 
-@pytest.mark.parametrize("R", [16, 64, 2048])
-def test_paired_launches_give_the_bits_of_the_interfaces_separate_ones(gpu, oracle_fast, R):
+@pytest.mark.parametrize("R,S", [(16, 128), (64, 128), (2048, 128), (1311, 100)])
+def test_paired_launches_give_the_bits_of_the_interfaces_separate_ones(gpu, oracle_fast, R, S):
     """The training step sends a layer's weight gradient and the data gradient made from the same error
     matrix to the GPU as one launch (64x64 tiles at 16 and 64 rays, 128x128 at 2048); the reference's own
     call sequence (forward_pass_mlp / backward_pass_mlp, train.c:188-216) launches every product alone.
     Fed the step's encoded batch and output error, it must arrive at the same gradients bit for bit."""
     from nerf_amd.api import DeviceArray, Trainer
     from nerf_amd._lib import lib
-    S = 128
     p = Pair(gpu, oracle_fast, R, S, n_images=4)
     p.tr.forward_backward(p.dds, DeviceArray.from_numpy(p.indices(77)))
     grads, _ = p.tr.get_grads()
