@@ -185,20 +185,43 @@ __global__ __launch_bounds__(256) void skinny_backward_kernel(const float* __res
 // contraction off (file-wide pragma below the includes) and hipcc's correctly rounded sqrtf and '/',
 // so results are bit-reproducible across host and device.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adamw_element(float& w, float g, float& m, float& v, float grad_div, float beta1,
+                                              float beta2, float c1, float c2, float eps, float alpha_t, float decay) {
+    const float gi = __fdiv_rn(g, grad_div);
+    const float mi = __fadd_rn(__fmul_rn(beta1, m), __fmul_rn(c1, gi));
+    const float vi = __fadd_rn(__fmul_rn(beta2, v), __fmul_rn(__fmul_rn(c2, gi), gi));
+    m = mi;
+    v = vi;
+    const float upd = __fdiv_rn(__fmul_rn(alpha_t, mi), __fadd_rn(sqrtf(vi), eps));
+    w = __fsub_rn(__fmul_rn(w, decay), upd);
+}
+
+// VEC = 4: four consecutive elements per thread in 16-byte pieces (arrays 16-byte aligned, n a multiple of 4);
+// the same operations per element either way
+template <int VEC>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, size_t n,
                                                     float grad_div, float beta1, float beta2, float eps,
                                                     float alpha_t, float decay) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * VEC;
     if (i >= n) return;
     const float c1 = __fsub_rn(1.0f, beta1), c2 = __fsub_rn(1.0f, beta2);
-    const float gi = __fdiv_rn(g[i], grad_div);
-    const float mi = __fadd_rn(__fmul_rn(beta1, m[i]), __fmul_rn(c1, gi));
-    const float vi = __fadd_rn(__fmul_rn(beta2, v[i]), __fmul_rn(__fmul_rn(c2, gi), gi));
-    m[i] = mi;
-    v[i] = vi;
-    const float upd = __fdiv_rn(__fmul_rn(alpha_t, mi), __fadd_rn(sqrtf(vi), eps));
-    w[i] = __fsub_rn(__fmul_rn(w[i], decay), upd);
+    if (VEC == 4) {
+        f32x4 wi = *reinterpret_cast<const f32x4*>(w + i), mi = *reinterpret_cast<const f32x4*>(m + i);
+        f32x4 vi = *reinterpret_cast<const f32x4*>(v + i);
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(g + i);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float wk = wi[k], mk = mi[k], vk = vi[k];
+            adamw_element(wk, gi[k], mk, vk, grad_div, beta1, beta2, c1, c2, eps, alpha_t, decay);
+            wi[k] = wk; mi[k] = mk; vi[k] = vk;
+        }
+        *reinterpret_cast<f32x4*>(m + i) = mi;
+        *reinterpret_cast<f32x4*>(v + i) = vi;
+        *reinterpret_cast<f32x4*>(w + i) = wi;
+    } else {
+        adamw_element(w[i], g[i], m[i], v[i], grad_div, beta1, beta2, c1, c2, eps, alpha_t, decay);
+    }
 }
 
 bool skinny_ok_impl(int hidden, int out_dim) {
@@ -288,8 +311,13 @@ void skinny_backward(const float* E, const float* Hpre, const float* W2, float* 
 void adamw_update(float* w, const float* g, float* m, float* v, size_t n, float grad_div, float beta1, float beta2,
                   float eps, float alpha_t, float decay) {
     ProfScope prof(K_ADAMW, (double)n * 28.0);
-    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), w, g, m, v, n,
-                       grad_div, beta1, beta2, eps, alpha_t, decay);
+    const bool vec = n % 4 == 0 && (((uintptr_t)w | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(adamw_kernel<4>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream(), w, g, m, v, n,
+                           grad_div, beta1, beta2, eps, alpha_t, decay);
+    else
+        hipLaunchKernelGGL(adamw_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream(), w, g, m, v, n,
+                           grad_div, beta1, beta2, eps, alpha_t, decay);
 }
 
 // ---- MLP pieces shared with the trainer --------------------------------------------------------
