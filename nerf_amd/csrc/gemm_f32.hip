@@ -175,7 +175,11 @@ template __global__ void gemm_dma_kernel<true, false, 2, 2, 2, 2, 16>(const Kern
 // Same contraction order as gemm_dma_kernel: the same bits.
 constexpr int RING = 5, RING_TILE = 128 * 16;  // floats per staged tile pair: [64 x 16] of A, then of B
 
-template <bool A_KC, bool B_KC, int SLOT>
+// IL: the fragment reads of the next eight steps are placed BETWEEN the four matrix instructions of the
+// current eight (each of which waits for the one before it: the reads issue during that wait) instead of in
+// front of them.  With one or two wavefronts per SIMD nothing else fills those issue slots; with the eight
+// of a full pair launch the plain order is the faster one (measured), so the launcher chooses.
+template <bool A_KC, bool B_KC, int SLOT, bool IL>
 __device__ __forceinline__ void ring_tile(float (&lds)[RING][RING_TILE], const DmaLoader<A_KC, 64, 256, 16>& da,
                                           const DmaLoader<B_KC, 64, 256, 16>& db, f32x16& acc, float (&fa)[2][4],
                                           float (&fb)[2][4], int next, int wave, int wm, int wn, int lane) {
@@ -188,18 +192,33 @@ __device__ __forceinline__ void ring_tile(float (&lds)[RING][RING_TILE], const D
     // steps 8..15 of this tile, then (fa[0], fb[0] hold steps 0..7 on entry) the matrix instructions
     dma_frag<A_KC, 64, 16>(fa[1], lds[SLOT], wm * 32, 1, lane);
     dma_frag<B_KC, 64, 16>(fb[1], lds[SLOT] + 64 * 16, wn * 32, 1, lane);
-    __builtin_amdgcn_sched_barrier(0);
+    if (!IL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][j], fb[0][j], acc, 0, 0, 0);
+    if (IL) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one matrix instruction,
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // then up to two LDS reads
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     dma_frag<A_KC, 64, 16>(fa[0], lds[NEXT], wm * 32, 0, lane);
     dma_frag<B_KC, 64, 16>(fb[0], lds[NEXT] + 64 * 16, wn * 32, 0, lane);
-    __builtin_amdgcn_sched_barrier(0);
+    if (!IL) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][j], fb[1][j], acc, 0, 0, 0);
+    if (IL) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool IL>
 __device__ __forceinline__ void ring_product(const KernelArgs& ka, float (&lds)[RING][RING_TILE], int block) {
     const GemmArgs& p = ka.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -237,16 +256,16 @@ __device__ __forceinline__ void ring_product(const KernelArgs& ka, float (&lds)[
         auto at = [&](int t) { return t < last ? t : last; };
         int kt = 0;
         for (; kt + RING <= nkt; kt += RING) {
-            ring_tile<A_KC, B_KC, 0>(lds, da, db, acc[0][0], fa, fb, at(kt + 4), wave, wm, wn, lane);
-            ring_tile<A_KC, B_KC, 1>(lds, da, db, acc[0][0], fa, fb, at(kt + 5), wave, wm, wn, lane);
-            ring_tile<A_KC, B_KC, 2>(lds, da, db, acc[0][0], fa, fb, at(kt + 6), wave, wm, wn, lane);
-            ring_tile<A_KC, B_KC, 3>(lds, da, db, acc[0][0], fa, fb, at(kt + 7), wave, wm, wn, lane);
-            ring_tile<A_KC, B_KC, 4>(lds, da, db, acc[0][0], fa, fb, at(kt + 8), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 0, IL>(lds, da, db, acc[0][0], fa, fb, at(kt + 4), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 1, IL>(lds, da, db, acc[0][0], fa, fb, at(kt + 5), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 2, IL>(lds, da, db, acc[0][0], fa, fb, at(kt + 6), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 3, IL>(lds, da, db, acc[0][0], fa, fb, at(kt + 7), wave, wm, wn, lane);
+            ring_tile<A_KC, B_KC, 4, IL>(lds, da, db, acc[0][0], fa, fb, at(kt + 8), wave, wm, wn, lane);
         }
-        if (kt < nkt) ring_tile<A_KC, B_KC, 0>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
-        if (kt + 1 < nkt) ring_tile<A_KC, B_KC, 1>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
-        if (kt + 2 < nkt) ring_tile<A_KC, B_KC, 2>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
-        if (kt + 3 < nkt) ring_tile<A_KC, B_KC, 3>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
+        if (kt < nkt) ring_tile<A_KC, B_KC, 0, IL>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
+        if (kt + 1 < nkt) ring_tile<A_KC, B_KC, 1, IL>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
+        if (kt + 2 < nkt) ring_tile<A_KC, B_KC, 2, IL>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
+        if (kt + 3 < nkt) ring_tile<A_KC, B_KC, 3, IL>(lds, da, db, acc[0][0], fa, fb, last, wave, wm, wn, lane);
         // the tiles fetched past the end are still landing: let them, before the LDS is handed back
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -255,16 +274,20 @@ __device__ __forceinline__ void ring_product(const KernelArgs& ka, float (&lds)[
 template <bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 3) void gemm_dma_ring_kernel(const KernelArgs ka) {
     __shared__ __attribute__((aligned(16))) float lds[RING][RING_TILE];
-    ring_product<A_KC, B_KC>(ka, lds, blockIdx.x);
+    ring_product<A_KC, B_KC, true>(ka, lds, blockIdx.x);
 }
 
 // Two products that do not depend on each other as one launch: the first blocks_a workgroups work on the
 // first (a weight gradient: both operands strided), the rest on the second (a data gradient: A k-contiguous).
+template <bool IL>
 __global__ __launch_bounds__(256, 3) void gemm_dma_ring_pair_kernel(const PairArgs pa) {
     __shared__ __attribute__((aligned(16))) float lds[RING][RING_TILE];
-    if (blockIdx.x < pa.blocks_a) ring_product<false, false>(pa.a, lds, blockIdx.x);
-    else ring_product<true, false>(pa.b, lds, blockIdx.x - pa.blocks_a);
+    if (blockIdx.x < pa.blocks_a) ring_product<false, false, IL>(pa.a, lds, blockIdx.x);
+    else ring_product<true, false, IL>(pa.b, lds, blockIdx.x - pa.blocks_a);
 }
+template __global__ void gemm_dma_ring_pair_kernel<false>(const PairArgs);
+template __global__ void gemm_dma_ring_pair_kernel<true>(const PairArgs);
+
 template __global__ void gemm_dma_ring_kernel<true, true>(const KernelArgs);
 template __global__ void gemm_dma_ring_kernel<true, false>(const KernelArgs);
 template __global__ void gemm_dma_ring_kernel<false, false>(const KernelArgs);
@@ -646,7 +669,10 @@ void launch_dma_small(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
             pa.blocks_a = (unsigned)g_held.grid;
             g_held.held = false;
             prof_redirect_scope(K_GEMM_PAIR, g_held.work());
-            hipLaunchKernelGGL(gemm_dma_ring_pair_kernel, dim3((unsigned)(g_held.grid + grid)), dim3(256), 0, stream(), pa);
+            // up to two workgroups per CU: reads between the matrix instructions (ring_tile)
+            const unsigned blocks = (unsigned)(g_held.grid + grid);
+            if (blocks <= 512) hipLaunchKernelGGL(gemm_dma_ring_pair_kernel<true>, dim3(blocks), dim3(256), 0, stream(), pa);
+            else hipLaunchKernelGGL(gemm_dma_ring_pair_kernel<false>, dim3(blocks), dim3(256), 0, stream(), pa);
             return;
         }
         release_held();
