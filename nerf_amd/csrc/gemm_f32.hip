@@ -669,9 +669,9 @@ void launch_dma_small(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
             pa.blocks_a = (unsigned)g_held.grid;
             g_held.held = false;
             prof_redirect_scope(K_GEMM_PAIR, g_held.work());
-            // up to two workgroups per CU: reads between the matrix instructions (ring_tile)
+            // up to four workgroups per CU, i.e. one round: reads between the matrix instructions (ring_tile)
             const unsigned blocks = (unsigned)(g_held.grid + grid);
-            if (blocks <= 512) hipLaunchKernelGGL(gemm_dma_ring_pair_kernel<true>, dim3(blocks), dim3(256), 0, stream(), pa);
+            if (blocks <= 1024) hipLaunchKernelGGL(gemm_dma_ring_pair_kernel<true>, dim3(blocks), dim3(256), 0, stream(), pa);
             else hipLaunchKernelGGL(gemm_dma_ring_pair_kernel<false>, dim3(blocks), dim3(256), 0, stream(), pa);
             return;
         }
