@@ -55,12 +55,22 @@ __global__ __launch_bounds__(256) void skinny_forward_kernel(const float* __rest
                                                              const float* __restrict__ W2, float* __restrict__ Y,
                                                              long rows, int hidden) {
     extern __shared__ __attribute__((aligned(16))) float w2s[];  // [OUT][hidden]
+    const int sub = threadIdx.x & 15;
+    const long rows_per_iter = (long)gridDim.x * 16;
+    const long row0 = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    // the first pieces of the first row are asked for before W2 is staged, so that the two round trips to
+    // memory overlap (a small batch is one row per 16 lanes: this launch is those two latencies)
+    f32x4 xs[4];
+    if (row0 < rows) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (sub * 4 + u * 64 < hidden)
+                xs[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Hact + row0 * hidden + sub * 4 + u * 64));
+    }
     for (int i = threadIdx.x * 4; i < OUT * hidden; i += 256 * 4)
         *reinterpret_cast<f32x4*>(w2s + i) = *reinterpret_cast<const f32x4*>(W2 + i);
     __syncthreads();
-    const int sub = threadIdx.x & 15;
-    const long rows_per_iter = (long)gridDim.x * 16;
-    for (long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4); row < rows; row += rows_per_iter) {
+    for (long row = row0; row < rows; row += rows_per_iter) {
         const float* h = Hact + row * hidden;
         float acc[OUT];
 #pragma unroll
@@ -68,10 +78,11 @@ __global__ __launch_bounds__(256) void skinny_forward_kernel(const float* __rest
         // four 16-byte pieces of the row are asked for before the first is used (a lane's share of a
         // 512-wide row is eight): the sums still take the columns in ascending order
         for (int c0 = sub * 4; c0 < hidden; c0 += 256) {
-            f32x4 xs[4];
+            if (row != row0 || c0 != sub * 4) {
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (c0 + u * 64 < hidden) xs[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h + c0 + u * 64));
+                for (int u = 0; u < 4; u++)
+                    if (c0 + u * 64 < hidden) xs[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(h + c0 + u * 64));
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int c = c0 + u * 64;
