@@ -54,8 +54,10 @@ struct ProfScope {
 // What gemm_f32 tells the ProfScope its caller has open around the call.  prof_discard_scope(): the
 // product was held back and nothing was launched -- the scope records nothing.  prof_redirect_scope(id,
 // extra): what was launched is a pair -- the scope records its time under `id`, with `extra` (the held
-// product's work) added to its own.
+// product's work) added to its own.  prof_restart_scope(): a held product was released (launched, with
+// timing of its own) inside the open scope -- the scope's time starts now, behind that launch.
 void prof_discard_scope();
+void prof_restart_scope();
 void prof_redirect_scope(int id, double extra_work);
 
 // ---- fp32 MFMA matrix product ---------------------------------------------------------------

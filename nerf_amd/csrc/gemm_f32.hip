@@ -621,20 +621,23 @@ void launch_ring_single(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
     else if (a_kc) hipLaunchKernelGGL((gemm_dma_ring_kernel<true, false>), dim3(grid), dim3(256), 0, stream(), ka);
     else hipLaunchKernelGGL((gemm_dma_ring_kernel<false, false>), dim3(grid), dim3(256), 0, stream(), ka);
 }
-void release_held() {
-    if (!g_held.held) return;
+bool release_held() {
+    if (!g_held.held) return false;
     g_held.held = false;
     // the caller's own timing scope recorded nothing when the product was held back (a held product is a
     // weight gradient): its launch is timed, and its work counted, here
-    ProfScope prof(K_GEMM_WGRAD, g_held.work());
-    if (g_held.big) hipLaunchKernelGGL((gemm_dma_kernel<false, false, 2, 2, 2, 2>), dim3(g_held.grid), dim3(256), 0, stream(), g_held.ka);
-    else launch_ring_single(g_held.ka, g_held.grid, g_held.a_kc, g_held.b_kc);
+    {
+        ProfScope prof(K_GEMM_WGRAD, g_held.work());
+        if (g_held.big) hipLaunchKernelGGL((gemm_dma_kernel<false, false, 2, 2, 2, 2>), dim3(g_held.grid), dim3(256), 0, stream(), g_held.ka);
+        else launch_ring_single(g_held.ka, g_held.grid, g_held.a_kc, g_held.b_kc);
+    }
+    return true;
 }
 // the large-tile counterparts of launch_dma_small: a split-K weight gradient is held back, a data gradient
 // that comes right after it joins it
 bool hold_big_wgrad(const KernelArgs& ka, int grid) {
     if (g_pair_depth == 0) return false;
-    release_held();
+    (void)release_held();
     g_held = HeldProduct{ka, grid, 0, 0, true, true};
     prof_discard_scope();  // nothing launched: the pair's launch (or the release) accounts for this product
     return true;
@@ -660,7 +663,7 @@ void launch_dma_small(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
     // from one error matrix.  The other order -- a data gradient, then the weight gradient of the layer
     // below, which READS that data gradient -- must never share a launch.
     const bool strided = !a_kc && !b_kc, half = a_kc && !b_kc;
-    if (g_held.held && g_held.big) release_held();
+    if (g_held.held && g_held.big && release_held()) prof_restart_scope();
     if (g_held.held) {
         if (half) {
             PairArgs pa;
@@ -675,7 +678,7 @@ void launch_dma_small(const KernelArgs& ka, int grid, int a_kc, int b_kc) {
             else hipLaunchKernelGGL(gemm_dma_ring_pair_kernel<false>, dim3(blocks), dim3(256), 0, stream(), pa);
             return;
         }
-        release_held();
+        if (release_held()) prof_restart_scope();
     }
     if (strided) {
         g_held = HeldProduct{ka, grid, a_kc, b_kc, true, false};
@@ -743,7 +746,7 @@ int gemm_f32(const GemmArgs& g) {
     const bool big_wgrad = dma && !small && !wide && !g.a_kc && !g.b_kc && g.epilogue == EPI_SPLITK;
     const bool big_dgrad = dma && !small && g.a_kc && !g.b_kc;
     if (big_dgrad && join_big_dgrad(ka, gi)) return hipGetLastError() == hipSuccess ? NERF_OK : NERF_ERR_HIP;
-    if (!(dma && small)) release_held();  // launches keep the order of the calls
+    if (!(dma && small) && release_held()) prof_restart_scope();  // launches keep the order of the calls
     if (big_wgrad && hold_big_wgrad(ka, gi)) return NERF_OK;
     if (dma) {
         // 16-step K-tiles (32 KB of LDS, four workgroups per CU) for the products that store a
@@ -777,7 +780,7 @@ GemmPairScope::GemmPairScope(bool enable) : on_(enable) {
     if (on_) g_pair_depth++;
 }
 GemmPairScope::~GemmPairScope() {
-    if (on_ && --g_pair_depth == 0) release_held();
+    if (on_ && --g_pair_depth == 0) (void)release_held();
 }
 
 void reduce_slabs(const float* slabs, int splits, size_t stride, float* dst, size_t n, int accumulate) {

@@ -28,6 +28,7 @@ const char* const g_prof_names[K_COUNT] = {
 thread_local bool g_prof_discard = false;
 thread_local int g_prof_redirect = -1;
 thread_local double g_prof_extra = 0.0;
+thread_local hipEvent_t g_prof_restart = nullptr;
 
 void prof_drain() {
     for (ProfRecord& r : g_prof_pending) {
@@ -62,6 +63,16 @@ ProfScope::~ProfScope() {
     g_prof_discard = false;
     g_prof_redirect = -1;
     g_prof_extra = 0.0;
+    hipEvent_t restart = g_prof_restart;
+    g_prof_restart = nullptr;
+    if (restart) {  // another product's launch went out inside this scope: this one's time starts after it
+        if (start_) {
+            (void)hipEventDestroy((hipEvent_t)start_);
+            start_ = (void*)restart;
+        } else {
+            (void)hipEventDestroy(restart);
+        }
+    }
     if (!start_) return;
     if (discard) {
         (void)hipEventDestroy((hipEvent_t)start_);
@@ -74,6 +85,14 @@ ProfScope::~ProfScope() {
 }
 
 void prof_discard_scope() { g_prof_discard = true; }
+void prof_restart_scope() {
+    if (!g_prof_on) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, g_stream);
+    if (g_prof_restart) (void)hipEventDestroy(g_prof_restart);
+    g_prof_restart = e;
+}
 void prof_redirect_scope(int id, double extra_work) {
     g_prof_redirect = id;
     g_prof_extra = extra_work;
