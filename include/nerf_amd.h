@@ -35,6 +35,11 @@ void nerf_device_free(void* p);
  * each way against 17-37 GB/s from pageable memory).  NULL on failure. */
 void* nerf_host_alloc(size_t bytes);
 void nerf_host_free(void* p);
+/* No counterpart in train.c: the address under which the GPU sees memory from nerf_host_alloc, or NULL.  A
+ * kernel argument may point there: a few hundred bytes a step (the ray indices of a small batch) are then read
+ * over the link by the kernel that wants them, and no copy is enqueued at all.  The memory must stay untouched
+ * until the stream has passed that kernel. */
+void* nerf_host_device_pointer(void* p);
 /* generate_random_batch and batch_positional_encoding (nerf_kernels.h) stage through device buffers
  * that the library keeps between calls; this frees them. */
 void nerf_host_api_release(void);

@@ -87,6 +87,7 @@ _SIGS = {
     "nerf_memcpy_h2d_async": (C.c_int, [VP, VP, C.c_size_t]),
     "nerf_host_alloc": (VP, [C.c_size_t]),
     "nerf_host_free": (None, [VP]),
+    "nerf_host_device_pointer": (VP, [VP]),
     "nerf_host_api_release": (None, []),
     "nerf_memcpy_d2h": (C.c_int, [VP, VP, C.c_size_t]),
     "nerf_memcpy_d2d": (C.c_int, [VP, VP, C.c_size_t]),

@@ -139,6 +139,14 @@ void nerf_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
+// The device's address of memory from nerf_host_alloc (NULL if it has none): kernels may read small inputs
+// straight from the host through it.
+void* nerf_host_device_pointer(void* p) {
+    void* d = nullptr;
+    if (!p || hipHostGetDevicePointer(&d, p, 0) != hipSuccess) return nullptr;
+    return d;
+}
+
 int nerf_memcpy_h2d(void* dst, const void* src, size_t bytes) {
     if (hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, nerf::g_stream) != hipSuccess) return NERF_ERR_HIP;
     return hipStreamSynchronize(nerf::g_stream) == hipSuccess ? NERF_OK : NERF_ERR_HIP;

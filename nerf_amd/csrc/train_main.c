@@ -348,18 +348,25 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
      * copy is enqueued without waiting (train.c:182-185 copies synchronously, which drains the GPU every
      * step), and a slot is drawn into again only after the stream has passed its previous copy.  The host
      * thus draws the next batches while the GPU works on this one; it is waited for only where the loss is
-     * read. */
-    enum { IDX_SLOTS = 4 };
+     * read.  A small batch (up to ZERO_COPY_RAYS rays: 3 KB) is not copied at all: the encoder reads the
+     * page-locked buffer over the link, and the slot's event is recorded behind the step that reads it. */
+    enum { IDX_SLOTS = 4, ZERO_COPY_RAYS = 256 };
     int* idx_ring[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
     int* d_idx_ring[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
     void* idx_copied[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
     int idx_used[IDX_SLOTS] = {0, 0, 0, 0};
     long slot_counter = 0;
     const size_t idx_bytes = (size_t)o.rays * 3 * sizeof(int);
+    int zero_copy = o.rays <= ZERO_COPY_RAYS;
     if (o.fused) {
         for (int k = 0; k < IDX_SLOTS; k++) {
             idx_ring[k] = (int*)nerf_host_alloc(idx_bytes);
-            d_idx_ring[k] = (int*)device_alloc_or_die(idx_bytes);
+            if (zero_copy) {
+                d_idx_ring[k] = (int*)nerf_host_device_pointer(idx_ring[k]);
+                if (!d_idx_ring[k] && k == 0) zero_copy = 0; /* no device view of host memory here: copy as ever */
+                else if (!d_idx_ring[k]) return -1;
+            }
+            if (!zero_copy) d_idx_ring[k] = (int*)device_alloc_or_die(idx_bytes);
             idx_copied[k] = nerf_event_create();
             if (!idx_ring[k] || !idx_copied[k]) {
                 fprintf(stderr, "Failed to allocate the ray-index buffers\n");
@@ -396,11 +403,14 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
                 if (idx_used[k]) CHECK_HIP(nerf_event_synchronize(idx_copied[k]));
                 srand(batch_seed(seed_base, batch));
                 if (nerf_draw_ray_indices_shard(ds, o.rays * shards, v, shards, idx_ring[k]) != 0) return -1;
-                CHECK_HIP(nerf_memcpy_h2d_async(d_idx_ring[k], idx_ring[k], idx_bytes));
-                CHECK_HIP(nerf_event_record(idx_copied[k]));
+                if (!zero_copy) {
+                    CHECK_HIP(nerf_memcpy_h2d_async(d_idx_ring[k], idx_ring[k], idx_bytes));
+                    CHECK_HIP(nerf_event_record(idx_copied[k]));
+                }
                 idx_used[k] = 1;
                 if (v == 0) CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx_ring[k], NULL));
                 else CHECK_HIP(nerf_trainer_forward_backward_add(trainer, dds, d_idx_ring[k], NULL));
+                if (zero_copy) CHECK_HIP(nerf_event_record(idx_copied[k]));
             }
             CHECK_HIP(nerf_trainer_update(trainer, lr, points * shards));
         } else if (o.fused) {
@@ -411,10 +421,13 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
             } else {
                 nerf_draw_ray_indices(ds, o.rays, idx_ring[k]);
             }
-            CHECK_HIP(nerf_memcpy_h2d_async(d_idx_ring[k], idx_ring[k], idx_bytes));
-            CHECK_HIP(nerf_event_record(idx_copied[k]));
+            if (!zero_copy) {
+                CHECK_HIP(nerf_memcpy_h2d_async(d_idx_ring[k], idx_ring[k], idx_bytes));
+                CHECK_HIP(nerf_event_record(idx_copied[k]));
+            }
             idx_used[k] = 1;
             CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx_ring[k], NULL));
+            if (zero_copy) CHECK_HIP(nerf_event_record(idx_copied[k]));
             if (dp) CHECK_HIP(nerf_dp_allreduce_grads(dp, trainer)); /* gradients and squared error of all ranks */
             CHECK_HIP(nerf_trainer_update(trainer, lr, points * world));
         } else {
@@ -457,7 +470,7 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
     if (o.fused) {
         for (int k = 0; k < IDX_SLOTS; k++) {
             nerf_host_free(idx_ring[k]);
-            nerf_device_free(d_idx_ring[k]);
+            if (!zero_copy) nerf_device_free(d_idx_ring[k]);
             nerf_event_destroy(idx_copied[k]);
         }
         nerf_dataset_release(dds);
