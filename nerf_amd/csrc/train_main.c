@@ -348,13 +348,14 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
      * copy is enqueued without waiting (train.c:182-185 copies synchronously, which drains the GPU every
      * step), and a slot is drawn into again only after the stream has passed its previous copy.  The host
      * thus draws the next batches while the GPU works on this one; it is waited for only where the loss is
-     * read.  A small batch (up to ZERO_COPY_RAYS rays: 3 KB) is not copied at all: the encoder reads the
+     * read.  Events are recorded behind every IDX_GROUP-th slot only (a slot waits for the event that closed its
+     * group the last time round: the host may run up to five steps ahead).  A small batch (up to ZERO_COPY_RAYS rays: 3 KB) is not copied at all: the encoder reads the
      * page-locked buffer over the link, and the slot's event is recorded behind the step that reads it. */
-    enum { IDX_SLOTS = 4, ZERO_COPY_RAYS = 256 };
-    int* idx_ring[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
-    int* d_idx_ring[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
-    void* idx_copied[IDX_SLOTS] = {NULL, NULL, NULL, NULL};
-    int idx_used[IDX_SLOTS] = {0, 0, 0, 0};
+    enum { IDX_SLOTS = 8, IDX_GROUP = 4, ZERO_COPY_RAYS = 256 };
+    int* idx_ring[IDX_SLOTS] = {NULL};
+    int* d_idx_ring[IDX_SLOTS] = {NULL};
+    void* idx_copied[IDX_SLOTS] = {NULL};
+    int idx_used[IDX_SLOTS] = {0};
     long slot_counter = 0;
     const size_t idx_bytes = (size_t)o.rays * 3 * sizeof(int);
     int zero_copy = o.rays <= ZERO_COPY_RAYS;
@@ -400,22 +401,24 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
             /* what `shards` ranks do, one after the other: every shard is cut from the same global draw */
             for (int v = 0; v < shards; v++) {
                 const int k = (int)(slot_counter++ % IDX_SLOTS);
-                if (idx_used[k]) CHECK_HIP(nerf_event_synchronize(idx_copied[k]));
+                const int group_end = (k & (IDX_GROUP - 1)) == IDX_GROUP - 1;
+                if (idx_used[k | (IDX_GROUP - 1)]) CHECK_HIP(nerf_event_synchronize(idx_copied[k | (IDX_GROUP - 1)]));
                 srand(batch_seed(seed_base, batch));
                 if (nerf_draw_ray_indices_shard(ds, o.rays * shards, v, shards, idx_ring[k]) != 0) return -1;
                 if (!zero_copy) {
                     CHECK_HIP(nerf_memcpy_h2d_async(d_idx_ring[k], idx_ring[k], idx_bytes));
-                    CHECK_HIP(nerf_event_record(idx_copied[k]));
+                    if (group_end) CHECK_HIP(nerf_event_record(idx_copied[k]));
                 }
                 idx_used[k] = 1;
                 if (v == 0) CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx_ring[k], NULL));
                 else CHECK_HIP(nerf_trainer_forward_backward_add(trainer, dds, d_idx_ring[k], NULL));
-                if (zero_copy) CHECK_HIP(nerf_event_record(idx_copied[k]));
+                if (zero_copy && group_end) CHECK_HIP(nerf_event_record(idx_copied[k]));
             }
             CHECK_HIP(nerf_trainer_update(trainer, lr, points * shards));
         } else if (o.fused) {
             const int k = (int)(slot_counter++ % IDX_SLOTS);
-            if (idx_used[k]) CHECK_HIP(nerf_event_synchronize(idx_copied[k]));
+            const int group_end = (k & (IDX_GROUP - 1)) == IDX_GROUP - 1;
+            if (idx_used[k | (IDX_GROUP - 1)]) CHECK_HIP(nerf_event_synchronize(idx_copied[k | (IDX_GROUP - 1)]));
             if (dp) { /* this rank's block of the global batch */
                 if (nerf_draw_ray_indices_shard(ds, o.rays * world, rank, world, idx_ring[k]) != 0) return -1;
             } else {
@@ -423,11 +426,11 @@ static int train_run(Options o, Dataset* ds, int rank, int world, const char* id
             }
             if (!zero_copy) {
                 CHECK_HIP(nerf_memcpy_h2d_async(d_idx_ring[k], idx_ring[k], idx_bytes));
-                CHECK_HIP(nerf_event_record(idx_copied[k]));
+                if (group_end) CHECK_HIP(nerf_event_record(idx_copied[k]));
             }
             idx_used[k] = 1;
             CHECK_HIP(nerf_trainer_forward_backward(trainer, dds, d_idx_ring[k], NULL));
-            if (zero_copy) CHECK_HIP(nerf_event_record(idx_copied[k]));
+            if (zero_copy && group_end) CHECK_HIP(nerf_event_record(idx_copied[k]));
             if (dp) CHECK_HIP(nerf_dp_allreduce_grads(dp, trainer)); /* gradients and squared error of all ranks */
             CHECK_HIP(nerf_trainer_update(trainer, lr, points * world));
         } else {
