@@ -612,7 +612,7 @@ def main():
         kernel_label = f"{GEMM_KERNEL[dom]} ({dom}: v_mfma_f32_32x32x2_f32, 128x128x{ksteps} tiles, LDS-DMA staged)"
         if dom == "gemm_pair":
             kernel_label += ("; one launch = the split-K weight gradient of a layer and the data gradient that the "
-                             "backward pass makes from the same error matrix, 512 + 16384 workgroups")
+                             f"backward pass makes from the same error matrix, 512 + {(R * S + 127) // 128 * 4} workgroups")
         peak = PEAK_F32_MFMA_TFLOPS
         if split:
             # three bf16 products are executed per algorithmic product: price the executed work
